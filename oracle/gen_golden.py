@@ -1,0 +1,196 @@
+"""Golden-vector generator -- TEST INFRASTRUCTURE ONLY (runs in the build container only).
+
+Pins ``oracle/unet_ref.py`` against the reference's OWN classes.  The reference module
+cannot be imported (``import monai`` -> ModuleNotFoundError, an ordinary Python error),
+so the three pure-torch classes ``DownSampleConv`` / ``Discriminator`` / ``Generator``
+(src/model.py:15-92) are AST-extracted and exec'd here, in memory, with a stand-in for
+``mainets.nets.BasicUNet`` (= the oracle's restated BasicUNet; MONAI itself is absent, so
+that part stays UNPINNED).  Nothing from the reference is written to the repo: only
+numeric inputs/outputs go to tests/golden/*.npz.  /root/reference does not exist on the
+GPU box, so this script is never run there.
+
+Usage:  python oracle/gen_golden.py [--ref /root/reference] [--out tests/golden]
+"""
+from __future__ import annotations
+
+import argparse
+import ast
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import unet_ref as R  # noqa: E402
+
+WANTED = ("Generator", "DownSampleConv", "Discriminator")
+
+
+def load_reference_classes(ref_root: str):
+    path = os.path.join(ref_root, "src", "model.py")
+    with open(path) as fh:
+        tree = ast.parse(fh.read(), filename=path)
+    body = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in WANTED]
+    assert sorted(n.name for n in body) == sorted(WANTED), "reference layout changed"
+    mod = ast.Module(body=body, type_ignores=[])
+    shim = types.SimpleNamespace(nets=types.SimpleNamespace(BasicUNet=R.RefBasicUNet))
+    ns = {"torch": torch, "mainets": shim}
+    exec(compile(mod, path, "exec"), ns)  # in-memory only
+    return {k: ns[k] for k in WANTED}
+
+
+def _grad_digest(module):
+    """Per-parameter (sum, abs-sum) of .grad, keyed by state_dict-style name."""
+    out = {}
+    for name, p in module.named_parameters():
+        if p.grad is None:
+            out[name] = np.array([np.nan, np.nan], dtype=np.float64)
+        else:
+            g = p.grad.double()
+            out[name] = np.array([g.sum().item(), g.abs().sum().item()])
+    return out
+
+
+def _param_digest(module):
+    return {n: np.array([p.detach().double().sum().item(), p.detach().double().abs().sum().item()])
+            for n, p in module.named_parameters()}
+
+
+def case_downsample(ref, out_dir):
+    DownSampleConv = ref["DownSampleConv"]
+    cfgs = {
+        "k1_bn_act": dict(in_channels=24, out_channels=24, kernel=1, strides=1, padding=0),
+        "k4s2_bn_act": dict(in_channels=32, out_channels=64),
+        "k4s2_nobn": dict(in_channels=30, out_channels=32, batchnorm=False),
+        "k4s2_noact": dict(in_channels=16, out_channels=32, activation=False),
+    }
+    store = {}
+    for i, (name, kw) in enumerate(cfgs.items()):
+        torch.manual_seed(100 + i)
+        m = DownSampleConv(**kw)
+        m.train()
+        g = torch.Generator().manual_seed(200 + i)
+        x = torch.rand(2, kw["in_channels"], 16, 16, 16, generator=g, requires_grad=True)
+        y = m(x)
+        w = torch.rand(y.shape, generator=g)
+        (y * w).sum().backward()
+        store[f"{name}/y"] = y.detach().numpy()
+        store[f"{name}/dx"] = x.grad.numpy()
+        for k, v in _grad_digest(m).items():
+            store[f"{name}/grad/{k}"] = v
+        if kw.get("batchnorm", True):
+            store[f"{name}/running_mean"] = m.bn.running_mean.numpy().copy()
+            store[f"{name}/running_var"] = m.bn.running_var.numpy().copy()
+        # eval-mode output with the updated running stats
+        m.eval()
+        with torch.no_grad():
+            store[f"{name}/y_eval"] = m(x.detach()).numpy()
+    np.savez_compressed(os.path.join(out_dir, "downsample_conv.npz"), **store)
+
+
+def case_discriminator(ref, out_dir):
+    Discriminator = ref["Discriminator"]
+    store = {}
+    for tag, modality, n, s, cin in (("bssfp_n1_s64", "bssfp", 1, 64, 24),
+                                     ("t1w_n2_s32", "t1w", 2, 32, 6)):
+        torch.manual_seed(7)
+        d = Discriminator(modality)
+        d.train()
+        x, y = R.synthetic_batch(n, s, seed=1234, cin=cin)
+        y.requires_grad_(True)
+        logits = d(x, y)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, torch.ones_like(logits))
+        loss.backward()
+        store[f"{tag}/logits"] = logits.detach().numpy()
+        store[f"{tag}/loss"] = np.array(loss.item())
+        # dy is large (6*s^3); keep a strided sample + digest
+        store[f"{tag}/dy_sample"] = y.grad[:, :, ::7, ::5, ::3].numpy().copy()
+        store[f"{tag}/dy_digest"] = np.array([y.grad.double().sum().item(),
+                                              y.grad.double().abs().sum().item()])
+        for k, v in _grad_digest(d).items():
+            store[f"{tag}/grad/{k}"] = v
+        store[f"{tag}/keys"] = np.array(sorted(d.state_dict().keys()))
+        store[f"{tag}/nparams"] = np.array(sum(p.numel() for p in d.parameters()))
+    np.savez_compressed(os.path.join(out_dir, "discriminator.npz"), **store)
+
+
+def case_generator(ref, out_dir):
+    """Reference ``Generator`` wiring (head sharing, head->unet order) with the oracle
+    BasicUNet standing in for MONAI's; plus BasicUNet self-regression vectors."""
+    Generator = ref["Generator"]
+    store = {}
+    for tag, modality, cin in (("bssfp", "bssfp", 24), ("dwi", "dwi-tensor", 6)):
+        torch.manual_seed(11)
+        g = Generator(modality)
+        # dropout off so that outputs are RNG-free (p is a plain attribute of the oracle ADN)
+        for m in g.modules():
+            if isinstance(m, R._RefADN):
+                m.p = 0.0
+        g.train()
+        x, y = R.synthetic_batch(1, 32, seed=4321, cin=cin)
+        x.requires_grad_(True)
+        y_hat = g(x)
+        loss = torch.nn.functional.l1_loss(y_hat, y)
+        loss.backward()
+        store[f"{tag}/y_hat"] = y_hat.detach().numpy()
+        store[f"{tag}/loss"] = np.array(loss.item())
+        store[f"{tag}/dx_sample"] = x.grad[:, :, ::5, ::3, ::2].numpy().copy()
+        for k, v in _grad_digest(g).items():
+            store[f"{tag}/grad/{k}"] = v
+        store[f"{tag}/keys"] = np.array(sorted(g.state_dict().keys()))
+        store[f"{tag}/nparams"] = np.array(sum(p.numel() for p in g.parameters()))
+        g.eval()
+        with torch.no_grad():
+            store[f"{tag}/y_hat_eval"] = g(x.detach()).numpy()
+    np.savez_compressed(os.path.join(out_dir, "generator.npz"), **store)
+
+
+def case_gan_step(ref, out_dir):
+    """Two full training steps (src/model.py:259-281 semantics) at 64^3, N=1, driven
+    through the reference's own Generator/Discriminator classes."""
+    torch.manual_seed(0)
+    gen = ref["Generator"]("bssfp")
+    for m in gen.modules():
+        if isinstance(m, R._RefADN):
+            m.p = 0.0
+    discr = ref["Discriminator"]("bssfp")
+    gen.train(), discr.train()
+    g_opt, d_opt = R.make_optimizers(gen, discr)
+    x, y = R.synthetic_batch(1, 64, seed=1234)
+    store = {}
+    for step in range(2):
+        logs = R.gan_training_step(gen, discr, g_opt, d_opt, x, y)
+        for k, v in logs.items():
+            store[f"step{step}/{k}"] = np.array(v.item())
+        for k, v in _param_digest(gen).items():
+            store[f"step{step}/gen/{k}"] = v
+        for k, v in _param_digest(discr).items():
+            store[f"step{step}/discr/{k}"] = v
+    gen.eval()
+    with torch.no_grad():
+        store["final/y_hat_eval_sample"] = gen(x)[:, :, ::4, ::4, ::4].numpy().copy()
+    np.savez_compressed(os.path.join(out_dir, "gan_step.npz"), **store)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    torch.set_num_threads(os.cpu_count() or 1)
+    os.makedirs(a.out, exist_ok=True)
+    ref = load_reference_classes(a.ref)
+    cases = dict(downsample=case_downsample, discriminator=case_discriminator,
+                 generator=case_generator, gan_step=case_gan_step)
+    for name, fn in cases.items():
+        if a.only and name != a.only:
+            continue
+        fn(ref, a.out)
+        print("wrote", name)
+
+
+if __name__ == "__main__":
+    main()
