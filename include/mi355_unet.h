@@ -1,0 +1,228 @@
+/*
+ * mi355_unet.h -- C ABI of the MI355X-native (gfx950 / CDNA4) 3D U-Net + PatchGAN hot path.
+ *
+ * Drop-in boundary.  The reference (SomeUserName1/UNet-bSSFP) has no
+ * FFI of its own: its hot path sits behind torch.nn.Module construction sites
+ *   - torch.nn.Conv3d / BatchNorm3d / LeakyReLU   in DownSampleConv   (src/model.py:50-57)
+ *   - mainets.nets.BasicUNet(...)                  in Generator        (src/model.py:22-28)
+ *   - the Discriminator layer list                                    (src/model.py:72-83)
+ * and torch.optim.AdamW (src/model.py:359-361).  Each entry point below names the reference
+ * operator it stands in for.  The Python side (unet_bssfp_amd/) binds these with ctypes
+ * (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; no torch types.  All pointers are DEVICE pointers owned by
+ *    the caller (PyTorch's caching allocator); the library never allocates, frees or keeps them.
+ *  - Every function launches only on the `stream` passed in (a hipStream_t) and never syncs.
+ *  - Return value: 0 on success, negative on error; mi355_last_error() gives the message
+ *    (thread-local).  No exceptions, no abort.
+ *  - Re-entrant: called from the main Python thread (forward) and the autograd thread (backward).
+ *  - Activation layout inside the path: NDHWC, element (n,d,h,w,c) at
+ *        ((((n*D + d)*H + h)*W + w) * ld + c),   ld >= C, C padded to a multiple of 16,
+ *    pad channels hold zeros.  `ld` lets a tensor be a channel slice of a wider buffer
+ *    (zero-copy skip-concat).  dtype: 0 = f32 (parity mode), 1 = bf16 (throughput mode;
+ *    f32 accumulate, f32 statistics, f32 master weights).
+ */
+#ifndef MI355_UNET_H
+#define MI355_UNET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_DT_F32 0
+#define MI355_DT_BF16 1
+
+#define MI355_OK 0
+#define MI355_ERR_ARG (-1)
+#define MI355_ERR_UNSUPPORTED (-2)
+#define MI355_ERR_HIP (-3)
+
+int mi355_version(void);
+const char* mi355_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Layout conversion at the module boundary.
+ * Reference: the NCDHW tensors handed to Generator.forward / Discriminator.forward
+ * (src/model.py:36-39, 85-92; torch.cat([x, y], 1) at :86 is realised by two packs into one
+ * 32-channel buffer).
+ * pack:   dst[n,d,h,w, coff + c] = src[n,c,d,h,w]  for c < C;  channels [coff+C, zero_to) = 0
+ * unpack: dst[n,c,d,h,w] = src[n,d,h,w, coff + c]
+ * src/dst NCDHW side is contiguous f32.  V = D*H*W.
+ * ---------------------------------------------------------------------------------------- */
+int mi355_pack_ncdhw(const float* src, void* dst, int32_t n, int32_t c, int64_t v,
+                     int32_t ld, int32_t coff, int32_t zero_to, int32_t dtype, void* stream);
+int mi355_unpack_ncdhw(const void* src, float* dst, int32_t n, int32_t c, int64_t v,
+                       int32_t ld, int32_t coff, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight packing.  Reference weights are torch layout: Conv3d (Cout,Cin,k,k,k) f32,
+ * ConvTranspose3d (Cin,Cout,2,2,2) f32 (SURVEY.md 8(b) state_dict table).
+ * dst[chunk][tap][co][16] (dtype) with ci = chunk*16 + e;  zero where co >= cout or ci >= cin.
+ * Source element for GEMM indices (co, ci, tap=(td,th,tw) in a ks^3 kernel):
+ *     src[co*s_co + ci*s_ci + kd*s_k[0] + kh*s_k[1] + kw*s_k[2]],  k* = tbase[*] + tstep[*]*t*
+ * which expresses forward, flipped/transposed (dgrad) and the parity classes of the
+ * stride-2 transposed convolutions without host-side tensor shuffles.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mi355_wpack_desc {
+  const float* src;
+  void* dst;
+  int32_t cout, cin;          /* real GEMM extents            */
+  int32_t coutp, cinp;        /* padded: coutp%32==0, cinp%16==0 */
+  int32_t ks;                 /* dst kernel edge (taps = ks^3)   */
+  int64_t s_co, s_ci;
+  int64_t s_k[3];
+  int32_t tbase[3], tstep[3];
+  int32_t dtype;
+} mi355_wpack_desc;
+int mi355_weight_pack(const mi355_wpack_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM 3D convolution on MFMA (forward of Conv3d; data-gradient of Conv3d and
+ * ConvTranspose3d; forward of ConvTranspose3d as 8 parity classes).
+ * Reference ops: torch.nn.Conv3d in DownSampleConv (src/model.py:50-51), Discriminator.final
+ * (:83), MONAI BasicUNet Convolution / final_conv / UpSample.deconv (call site :22-28).
+ *
+ *   z[n, p*os+ooff, co] = bias[co] + sum_{tap, ci} x[n, p*stride + tap - pad, ci] * w[tap][co][ci]
+ *   for p in the conv grid (do_,ho,wo); x is the virtual concat [x0 | x1] (x1 may be NULL).
+ * Out-of-range input positions read as zero.  Optional fused per-tile channel statistics of
+ * (z - bias): stats_part[tile][2][coutp] = {sum, sum of squares} (deterministic, no atomics);
+ * tiles are never shared between samples when ks==3 (InstanceNorm groups).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mi355_conv_desc {
+  const void* x0; int32_t c0; int32_t ld0;
+  const void* x1; int32_t c1; int32_t ld1;
+  int32_t n, di, hi, wi;          /* input spatial extents            */
+  int32_t do_, ho, wo;            /* conv grid extents                */
+  int32_t ks, stride;
+  int32_t pad[3];
+  const void* wp;                 /* packed weights, see mi355_weight_pack */
+  int32_t coutp;
+  const float* bias;              /* [coutp] f32 or NULL */
+  void* y; int32_t ldy; int32_t cstore;
+  int32_t dy, hy, wy;             /* physical output extents          */
+  int32_t os; int32_t ooff[3];
+  float* stats_part;              /* NULL or [mi355_conv_num_tiles()][2][coutp] */
+  int32_t dtype;
+} mi355_conv_desc;
+int mi355_conv_fwd(const mi355_conv_desc* d, void* stream);
+/* number of spatial tiles (= rows of stats_part) and tiles per sample (0 if tiles span samples) */
+int mi355_conv_num_tiles(const mi355_conv_desc* d, int32_t* tiles, int32_t* tiles_per_sample);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight gradient (autograd of Conv3d / ConvTranspose3d weights).
+ *   dw[tap][ci][co] = sum_{n,p} x[n, p*stride + tap - pad, ci] * g[n, p, co]
+ * computed as per-split partial slabs (deterministic) and reduced + scattered into the torch
+ * layout by mi355_wgrad_reduce: dst[co*s_co + ci*s_ci + tap offsets] (+)= sum_splits slab.
+ * workspace: mi355_conv_wgrad_workspace() bytes, f32.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mi355_wgrad_desc {
+  const void* x0; int32_t c0; int32_t ld0;
+  const void* x1; int32_t c1; int32_t ld1;
+  int32_t n, di, hi, wi;
+  const void* g; int32_t cg; int32_t ldg;   /* grad wrt conv output, cg channels (mult of 16) */
+  int32_t do_, ho, wo;                      /* extents of g's grid */
+  int32_t gd, gh, gw;                       /* physical extents of g */
+  int32_t gs; int32_t goff[3];              /* g position = p*gs + goff (transposed-conv classes) */
+  int32_t ks, stride;
+  int32_t pad[3];
+  float* workspace; int64_t workspace_bytes;
+  /* destination (torch layout), real extents */
+  float* dw; int32_t cout, cin;
+  int64_t s_co, s_ci; int64_t s_k[3];
+  int32_t tbase[3], tstep[3];
+  int32_t accumulate;                       /* 0: overwrite, 1: add into dw */
+  int32_t dtype;
+} mi355_wgrad_desc;
+int64_t mi355_conv_wgrad_workspace(const mi355_wgrad_desc* d);
+int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Channel statistics and fused normalisation + dropout + LeakyReLU.
+ * Reference ops: torch.nn.BatchNorm3d + LeakyReLU(0.2) (src/model.py:53-57, 61-64) and MONAI ADN
+ * "NDA" = InstanceNorm3d(affine) -> Dropout(p) -> LeakyReLU(0.1) (BasicUNet, call site :22-28).
+ * Groups: InstanceNorm = one group per sample (groups = N); BatchNorm = one group (groups = 1).
+ * ---------------------------------------------------------------------------------------- */
+/* partial sums over voxel blocks: part[block][2][c] of x (f32 accumulate); rows = N*V.
+ * blocks never span groups: blocks_per_group = ceil(rows_per_group / rows_per_block). */
+int mi355_channel_stats(const void* x, int32_t ld, int32_t c, int64_t rows_per_group, int32_t groups,
+                        float* part, int32_t blocks_per_group, int32_t dtype, void* stream);
+int32_t mi355_channel_stats_blocks(int64_t rows_per_group);
+
+/* mean/rstd per (group, channel) from partials (f64 combine).  shift[c] (may be NULL) is added to
+ * the mean (conv bias when partials were taken before the bias add).  Optionally updates
+ * BatchNorm running stats: rm = (1-mom)*rm + mom*mean, rv = (1-mom)*rv + mom*var*cnt/(cnt-1). */
+int mi355_norm_finalize(const float* part, int32_t parts_per_group, int32_t groups, int32_t c,
+                        int64_t count_per_group, const float* shift, float eps,
+                        float* mean, float* rstd,
+                        float* running_mean, float* running_var, float momentum, void* stream);
+
+typedef struct mi355_normact_desc {
+  const void* z; int32_t ldz;        /* conv output */
+  void* a; int32_t lda;              /* activated output (fwd) / unused (bwd) */
+  int32_t c; int64_t rows_per_group; int32_t groups;
+  const float* mean; const float* rstd;   /* [groups][c]; NULL => no normalisation */
+  const float* gamma; const float* beta;  /* [c]; NULL => 1 / 0 */
+  float slope;                            /* LeakyReLU negative slope; 1.0 => identity */
+  float drop_p; uint64_t seed;            /* element-wise dropout, p == 0 => off */
+  int32_t dtype;
+  /* backward only */
+  const void* da; int32_t ldda;
+  void* dz; int32_t lddz;
+  float* part;                            /* [blocks][2][c] partial sums of g and g*xhat */
+  int32_t blocks_per_group;
+  const float* sums;                      /* [groups][2][c] reduced sums (bwd_apply) */
+  int32_t batch_stats;                    /* 1: subtract mean terms (train), 0: eval-mode norm */
+} mi355_normact_desc;
+int mi355_normact_fwd(const mi355_normact_desc* d, void* stream);
+int mi355_normact_bwd_reduce(const mi355_normact_desc* d, void* stream);
+/* sums[g][2][c] = sum over blocks of part; dgamma[c] = sum_g sums[g][1][c], dbeta = sum_g sums[g][0][c] */
+int mi355_normact_bwd_finalize(const float* part, int32_t blocks_per_group, int32_t groups, int32_t c,
+                               float* sums, float* dgamma, float* dbeta, void* stream);
+int mi355_normact_bwd_apply(const mi355_normact_desc* d, void* stream);
+
+/* per-channel sum over all rows (bias gradient of a conv without normalisation):
+ * out[c] = sum_rows x[row][c] from channel_stats partials (parts x [2][c]) */
+int mi355_colsum_finalize(const float* part, int32_t parts, int32_t c, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * MaxPool3d(kernel_size=2) -- MONAI BasicUNet `Down` (call site src/model.py:22-28).
+ * Even extents only.  Backward routes the gradient to the first maximum in (d,h,w) scan order
+ * (torch CPU semantics) and writes zeros elsewhere (dx fully written).
+ * ---------------------------------------------------------------------------------------- */
+int mi355_maxpool2_fwd(const void* x, int32_t ldx, void* y, int32_t ldy, int32_t n, int32_t c,
+                       int32_t d, int32_t h, int32_t w, int32_t dtype, void* stream);
+int mi355_maxpool2_bwd(const void* x, int32_t ldx, const void* y, int32_t ldy,
+                       const void* dy, int32_t lddy, void* dx, int32_t lddx,
+                       int32_t n, int32_t c, int32_t d, int32_t h, int32_t w,
+                       int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Losses -- torch.nn.L1Loss (src/model.py:126,136): mean |a - b| over `count` f32 elements.
+ * fwd writes the scalar to out[0]; partials workspace >= mi355_l1_blocks(count) floats.
+ * bwd: da[i] = sign(a[i]-b[i]) * gscale[0] / count   (gscale is a DEVICE scalar: no host sync)
+ * ---------------------------------------------------------------------------------------- */
+int32_t mi355_l1_blocks(int64_t count);
+int mi355_l1_fwd(const float* a, const float* b, int64_t count, float* partials, float* out, void* stream);
+int mi355_l1_bwd(const float* a, const float* b, int64_t count, const float* gscale, float* da, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused multi-tensor AdamW -- torch.optim.AdamW(params, lr) with torch defaults
+ * (src/model.py:164, 359-361): decoupled weight decay, bias-corrected moments.
+ * ptrs: device array of 4*ntensors pointers {param, grad, exp_avg, exp_avg_sq} (all f32),
+ * sizes: device array of ntensors element counts; `step` is the 1-based step number.
+ * ---------------------------------------------------------------------------------------- */
+int mi355_adamw_multi(const void* const* ptrs, const int64_t* sizes, int32_t ntensors,
+                      int64_t max_size, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, int32_t step, void* stream);
+
+/* layout probe used by the tests: writes lane -> (row, col) maps of the MFMA accumulators */
+int mi355_mfma_selftest(float* out_f32_1024, float* out_bf16_1024, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_UNET_H */

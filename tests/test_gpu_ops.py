@@ -1,0 +1,303 @@
+"""GPU parity of every HIP kernel (through the C ABI) against plain PyTorch CPU f32 ops.
+
+Tolerances (f32 path): the f32 MFMA is an exact fmaf chain, so differences come only from the
+summation order: rtol 2e-4 / atol 2e-5 on O(1) data.  bf16 path (bf16 storage, f32 accumulate):
+rtol 3e-2 / atol 3e-2.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+TOL = {torch.float32: dict(rtol=2e-4, atol=2e-5), torch.bfloat16: dict(rtol=3e-2, atol=3e-2)}
+
+
+def _ops():
+    from unet_bssfp_amd import ops
+    return ops
+
+
+def to_act(x, dtype, cp=None):
+    """NCDHW f32 CPU tensor -> NDHWC activation on the GPU (channels padded to cp)."""
+    ops = _ops()
+    n, c, d, h, w = x.shape
+    cp = ops.round_up(c, 16) if cp is None else cp
+    out = ops.new_act(n, d, h, w, cp, dtype, DEV)
+    ops.pack_ncdhw(x.to(DEV).float().contiguous(), out, 0, cp)
+    return out
+
+
+def from_act(a, c):
+    return _ops().unpack_ncdhw(a, c, 0).cpu()
+
+
+def q(x, dtype):
+    """Round a CPU f32 tensor through `dtype` (so that the CPU reference sees the same inputs)."""
+    return x.to(dtype).to(torch.float32)
+
+
+def test_mfma_fragment_layout(hip):
+    a, b = _ops().mfma_selftest(DEV)
+    i = torch.arange(1, 33, dtype=torch.float32).view(32, 1)
+    j = torch.arange(1, 33, dtype=torch.float32).view(1, 32)
+    assert torch.equal(a.cpu(), i * 100.0 * j)           # D[i][j] = (i+1)*100*(j+1): asymmetric
+    assert torch.equal(b.cpu(), i * j + 0.5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pack_unpack_roundtrip(hip, dtype):
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(2, 24, 4, 6, 8, generator=g)
+    y = torch.rand(2, 6, 4, 6, 8, generator=g)
+    ops = _ops()
+    buf = ops.new_act(2, 4, 6, 8, 32, dtype, DEV)
+    buf.fill_(float("nan"))
+    ops.pack_ncdhw(x.to(DEV), buf, 0, 24)
+    ops.pack_ncdhw(y.to(DEV), buf, 24, 32)
+    full = buf.float().cpu()                              # (N,D,H,W,32)
+    ref = torch.cat([q(x, dtype), q(y, dtype), torch.zeros(2, 2, 4, 6, 8)], 1).permute(0, 2, 3, 4, 1)
+    assert torch.equal(full, ref)
+    assert torch.equal(ops.unpack_ncdhw(buf, 6, 24).cpu(), q(y, dtype))
+
+
+CONV_CASES = [
+    # name, N, Cin(s), Cout, spatial, ks, stride, pad
+    ("k3_wide", 1, (32,), 32, (4, 8, 32), 3, 1, 1),
+    ("k3_wide_ragged", 2, (16,), 32, (3, 5, 40), 3, 1, 1),
+    ("k3_mid_ct2", 1, (32,), 64, (4, 16, 16), 3, 1, 1),
+    ("k3_small", 2, (64,), 64, (8, 8, 8), 3, 1, 1),
+    ("k3_tiny", 1, (32,), 96, (2, 2, 2), 3, 1, 1),
+    ("k3_concat", 1, (32, 64), 32, (4, 4, 32), 3, 1, 1),
+    ("k3_cin24", 1, (24,), 32, (4, 4, 32), 3, 1, 1),
+    ("k4s2", 1, (30,), 32, (8, 8, 16), 4, 2, 1),
+    ("k4s2_ct2", 2, (32,), 64, (8, 8, 8), 4, 2, 1),
+    ("k1_head", 2, (24,), 24, (4, 4, 8), 1, 1, 0),
+    ("k1_final6", 1, (32,), 6, (4, 4, 8), 1, 1, 0),
+    ("k1_final1", 2, (512,), 1, (2, 2, 2), 1, 1, 0),
+]
+
+
+def _conv_layer(cins, cout, ks, stride, pad, seed):
+    from unet_bssfp_amd.nn import Conv3d
+    torch.manual_seed(seed)
+    return Conv3d(sum(cins), cout, ks, stride, pad)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_bwd(hip, case, dtype):
+    from unet_bssfp_amd import functional as Fn
+    name, n, cins, cout, sp, ks, stride, pad = case
+    g = torch.Generator().manual_seed(hash(name) % 1000)
+    layer = _conv_layer(cins, cout, ks, stride, pad, 1)
+    with torch.no_grad():
+        layer.weight.copy_(q(layer.weight, dtype))       # weights representable in the compute dtype
+    xs = [q(torch.rand(n, c, *sp, generator=g) - 0.3, dtype) for c in cins]
+    w_cpu = layer.weight.detach().clone().requires_grad_(True)
+    b_cpu = layer.bias.detach().clone().requires_grad_(True)
+    xcat = torch.cat(xs, 1).requires_grad_(True)
+    z_ref = F.conv3d(xcat, w_cpu, b_cpu, stride, pad)
+    gz = q(torch.rand(z_ref.shape, generator=g) - 0.5, dtype)
+    z_ref.backward(gz)
+
+    layer = layer.to(DEV)
+    acts = [to_act(x, dtype).requires_grad_(True) for x in xs]
+    z, part = Fn.ConvFn.apply(acts[0], acts[1] if len(acts) > 1 else None, layer.weight, layer.bias, layer.spec, True)
+    tol = TOL[dtype]
+    torch.testing.assert_close(from_act(z, cout), z_ref.detach(), **tol)
+    cp = z.shape[4]
+    if cp > cout:                                        # pad channels must hold zeros
+        assert float(z[..., cout:].abs().max()) == 0.0
+    # fused statistics of (z - bias): per-tile partial sums
+    s = part.sum(0).cpu()                                # [2][coutp]
+    zc = (z_ref.detach() - b_cpu.detach().view(1, -1, 1, 1, 1))
+    torch.testing.assert_close(s[0, :cout], zc.sum((0, 2, 3, 4)), rtol=2e-3, atol=2e-2 if dtype == torch.float32 else 0.5)
+    torch.testing.assert_close(s[1, :cout], (zc * zc).sum((0, 2, 3, 4)), rtol=2e-3 if dtype == torch.float32 else 2e-2, atol=1e-2)
+    # backward
+    z.backward(to_act(gz, dtype))
+    off = 0
+    btol = tol if dtype == torch.float32 else dict(rtol=5e-2, atol=1e-1)
+    for a, c in zip(acts, cins):
+        torch.testing.assert_close(from_act(a.grad, c), xcat.grad[:, off:off + c], **btol)
+        off += c
+    wscale = float(w_cpu.grad.abs().max())
+    torch.testing.assert_close(layer.weight.grad.cpu(), w_cpu.grad, rtol=tol["rtol"] * 5, atol=tol["atol"] * 5 * max(1.0, wscale))
+    torch.testing.assert_close(layer.bias.grad.cpu(), b_cpu.grad, rtol=tol["rtol"] * 5, atol=tol["atol"] * 50)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,sp", [(64, 64, (2, 4, 8)), (128, 64, (4, 4, 4))])
+def test_deconv_fwd_bwd(hip, dtype, cin, cout, sp):
+    from unet_bssfp_amd.nn import ConvTranspose3d
+    g = torch.Generator().manual_seed(5)
+    torch.manual_seed(2)
+    layer = ConvTranspose3d(cin, cout, 2, 2)
+    with torch.no_grad():
+        layer.weight.copy_(q(layer.weight, dtype))
+    x = q(torch.rand(2, cin, *sp, generator=g) - 0.4, dtype)
+    w_cpu = layer.weight.detach().clone().requires_grad_(True)
+    b_cpu = layer.bias.detach().clone().requires_grad_(True)
+    x_cpu = x.clone().requires_grad_(True)
+    z_ref = F.conv_transpose3d(x_cpu, w_cpu, b_cpu, stride=2)
+    gz = q(torch.rand(z_ref.shape, generator=g) - 0.5, dtype)
+    z_ref.backward(gz)
+    layer = layer.to(DEV)
+    a = to_act(x, dtype).requires_grad_(True)
+    z = layer.forward_act(a)
+    tol = TOL[dtype]
+    torch.testing.assert_close(from_act(z, cout), z_ref.detach(), **tol)
+    z.backward(to_act(gz, dtype))
+    btol = tol if dtype == torch.float32 else dict(rtol=5e-2, atol=1e-1)
+    torch.testing.assert_close(from_act(a.grad, cin), x_cpu.grad, **btol)
+    torch.testing.assert_close(layer.weight.grad.cpu(), w_cpu.grad, rtol=tol["rtol"] * 5, atol=tol["atol"] * 50)
+    torch.testing.assert_close(layer.bias.grad.cpu(), b_cpu.grad, rtol=tol["rtol"] * 5, atol=tol["atol"] * 50)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind,n,c,sp", [("instance", 2, 32, (4, 8, 8)), ("instance", 1, 64, (16, 16, 32)),
+                                         ("batch", 2, 24, (4, 4, 8)), ("batch", 3, 512, (2, 2, 2)),
+                                         ("none", 2, 32, (4, 4, 4))])
+def test_normact_fwd_bwd(hip, dtype, kind, n, c, sp):
+    from unet_bssfp_amd import functional as Fn
+    g = torch.Generator().manual_seed(7)
+    slope = 0.1 if kind == "instance" else 0.2
+    z = q(torch.randn(n, c, *sp, generator=g) * 1.5 + 0.7, dtype)
+    gamma = (torch.rand(c, generator=g) + 0.5)
+    beta = (torch.rand(c, generator=g) - 0.5)
+    z_cpu = z.clone().requires_grad_(True)
+    g_cpu, b_cpu = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = torch.zeros(c), torch.ones(c)
+    if kind == "instance":
+        y = F.instance_norm(z_cpu, None, None, g_cpu, b_cpu, True, 0.0, 1e-5)
+    elif kind == "batch":
+        y = F.batch_norm(z_cpu, rm, rv, g_cpu, b_cpu, True, 0.1, 1e-5)
+    else:
+        y = z_cpu
+    a_ref = F.leaky_relu(y, slope)
+    ga = q(torch.rand(a_ref.shape, generator=g) - 0.5, dtype)
+    a_ref.backward(ga)
+
+    cfg = Fn.NormCfg(kind, c, slope=slope)
+    zd = to_act(z, dtype).requires_grad_(True)
+    gd, bd = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+    rmd, rvd = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    if kind == "none":
+        a = Fn.NormActFn.apply(zd, None, None, None, None, cfg, True, None, None)
+    else:
+        a = Fn.NormActFn.apply(zd, None, gd, bd, None, cfg, True, rmd if kind == "batch" else None,
+                               rvd if kind == "batch" else None)
+    tol = TOL[dtype]
+    torch.testing.assert_close(from_act(a, c), a_ref.detach(), **tol)
+    a.backward(to_act(ga, dtype))
+    btol = dict(rtol=1e-3, atol=1e-5) if dtype == torch.float32 else dict(rtol=5e-2, atol=5e-2)
+    torch.testing.assert_close(from_act(zd.grad, c), z_cpu.grad, **btol)
+    if kind != "none":
+        nel = z.numel() / c
+        torch.testing.assert_close(gd.grad.cpu(), g_cpu.grad, rtol=1e-3 if dtype == torch.float32 else 5e-2, atol=1e-5 * nel if dtype == torch.float32 else 1e-2 * math.sqrt(nel))
+        torch.testing.assert_close(bd.grad.cpu(), b_cpu.grad, rtol=1e-3 if dtype == torch.float32 else 5e-2, atol=1e-5 * nel if dtype == torch.float32 else 1e-2 * math.sqrt(nel))
+    if kind == "batch":
+        torch.testing.assert_close(rmd.cpu(), rm, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(rvd.cpu(), rv, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batchnorm_eval_mode(hip, dtype):
+    from unet_bssfp_amd import functional as Fn
+    g = torch.Generator().manual_seed(9)
+    c = 32
+    z = q(torch.randn(2, c, 4, 4, 4, generator=g), dtype)
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.rand(c, generator=g) - 0.5
+    rm, rv = torch.rand(c, generator=g) - 0.5, torch.rand(c, generator=g) + 0.5
+    z_cpu = z.clone().requires_grad_(True)
+    a_ref = F.leaky_relu(F.batch_norm(z_cpu, rm.clone(), rv.clone(), gamma, beta, False, 0.1, 1e-5), 0.2)
+    ga = q(torch.rand(a_ref.shape, generator=g) - 0.5, dtype)
+    a_ref.backward(ga)
+    cfg = Fn.NormCfg("batch", c, slope=0.2)
+    zd = to_act(z, dtype).requires_grad_(True)
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    a = Fn.NormActFn.apply(zd, None, gamma.to(DEV), beta.to(DEV), None, cfg, False, rmd, rvd)
+    torch.testing.assert_close(from_act(a, c), a_ref.detach(), **TOL[dtype])
+    a.backward(to_act(ga, dtype))
+    torch.testing.assert_close(from_act(zd.grad, c), z_cpu.grad, **(TOL[dtype] if dtype == torch.float32 else dict(rtol=5e-2, atol=5e-2)))
+    assert torch.equal(rmd.cpu(), rm) and torch.equal(rvd.cpu(), rv)     # eval: buffers untouched
+
+
+def test_norm_single_value_raises(hip):
+    from unet_bssfp_amd import functional as Fn
+    z = to_act(torch.rand(1, 32, 1, 1, 1), torch.float32)
+    cfg = Fn.NormCfg("batch", 32, slope=0.2)
+    with pytest.raises(ValueError):
+        Fn.NormActFn.apply(z, None, torch.ones(32, device=DEV), torch.zeros(32, device=DEV), None, cfg, True,
+                           torch.zeros(32, device=DEV), torch.ones(32, device=DEV))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dropout_statistics_and_backward_mask(hip, dtype):
+    from unet_bssfp_amd import functional as Fn
+    torch.manual_seed(0)
+    c, p = 32, 0.05
+    z = q(torch.randn(1, c, 16, 16, 16), dtype)
+    cfg = Fn.NormCfg("instance", c, slope=0.1, p=p)
+    zd = to_act(z, dtype).requires_grad_(True)
+    ones, zeros = torch.ones(c, device=DEV), torch.zeros(c, device=DEV)
+    a = Fn.NormActFn.apply(zd, None, ones, zeros, None, cfg, True, None, None)
+    av = from_act(a, c)
+    dropped = (av == 0).float().mean().item()
+    assert abs(dropped - p) < 0.004                       # ~131k elements: sigma ~ 6e-4
+    ref = F.leaky_relu(F.instance_norm(z, eps=1e-5), 0.1) / (1 - p)
+    keep = av != 0
+    torch.testing.assert_close(av[keep], ref[keep], **TOL[dtype])
+    # eval mode: no dropout
+    a_eval = Fn.NormActFn.apply(zd, None, ones, zeros, None, cfg, False, None, None)
+    torch.testing.assert_close(from_act(a_eval, c), ref * (1 - p), **TOL[dtype])
+    # backward uses the same mask: dz is exactly 0-contribution where dropped => check via linearity
+    a.backward(to_act(torch.ones(1, c, 16, 16, 16), dtype))
+    assert torch.isfinite(zd.grad.float()).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_maxpool_fwd_bwd(hip, dtype):
+    from unet_bssfp_amd import functional as Fn
+    g = torch.Generator().manual_seed(11)
+    x = q(torch.randn(2, 32, 4, 8, 8, generator=g), dtype)
+    x[:, :, :2, :2, :2] = 0.0                             # ties: first max in scan order takes the gradient
+    x_cpu = x.clone().requires_grad_(True)
+    y_ref = F.max_pool3d(x_cpu, 2)
+    gy = q(torch.rand(y_ref.shape, generator=g), dtype)
+    y_ref.backward(gy)
+    xd = to_act(x, dtype).requires_grad_(True)
+    y = Fn.MaxPoolFn.apply(xd)
+    assert torch.equal(from_act(y, 32), y_ref.detach())
+    y.backward(to_act(gy, dtype))
+    assert torch.equal(from_act(xd.grad, 32), x_cpu.grad)
+
+
+def test_maxpool_odd_extent_is_rejected(hip):
+    from unet_bssfp_amd import _lib
+    with pytest.raises(_lib.Mi355Error):
+        _ops().maxpool2_fwd(to_act(torch.rand(1, 16, 3, 4, 4), torch.float32))
+
+
+def test_l1_loss_fwd_bwd(hip):
+    from unet_bssfp_amd import l1_loss
+    g = torch.Generator().manual_seed(13)
+    a = torch.rand(2, 6, 9, 10, 11, generator=g)
+    b = torch.rand(2, 6, 9, 10, 11, generator=g)
+    a_cpu = a.clone().requires_grad_(True)
+    (F.l1_loss(a_cpu, b) * 50.0).backward()
+    ad = a.to(DEV).requires_grad_(True)
+    loss = l1_loss(ad, b.to(DEV))
+    (loss * 50.0).backward()
+    torch.testing.assert_close(loss.cpu(), F.l1_loss(a, b), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(ad.grad.cpu(), a_cpu.grad, rtol=1e-6, atol=1e-10)
+
+
+def test_cpu_tensor_is_rejected_loudly(hip):
+    from unet_bssfp_amd import Generator, _lib
+    gen = Generator("bssfp")
+    with pytest.raises(_lib.Mi355Error):
+        gen(torch.rand(1, 24, 32, 32, 32))

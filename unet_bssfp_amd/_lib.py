@@ -1,0 +1,115 @@
+"""ctypes binding of the C-ABI library ``libmi355_unet.so`` (include/mi355_unet.h).
+
+The product path has NO fallback: if the library is missing or a call fails this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355_unet.so")
+
+DT_F32 = 0
+DT_BF16 = 1
+
+_i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
+
+
+class WpackDesc(C.Structure):
+    _fields_ = [("src", _vp), ("dst", _vp), ("cout", _i32), ("cin", _i32), ("coutp", _i32), ("cinp", _i32),
+                ("ks", _i32), ("s_co", _i64), ("s_ci", _i64), ("s_k", _i64 * 3),
+                ("tbase", _i32 * 3), ("tstep", _i32 * 3), ("dtype", _i32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("x0", _vp), ("c0", _i32), ("ld0", _i32), ("x1", _vp), ("c1", _i32), ("ld1", _i32),
+                ("n", _i32), ("di", _i32), ("hi", _i32), ("wi", _i32),
+                ("do_", _i32), ("ho", _i32), ("wo", _i32), ("ks", _i32), ("stride", _i32),
+                ("pad", _i32 * 3), ("wp", _vp), ("coutp", _i32), ("bias", _vp),
+                ("y", _vp), ("ldy", _i32), ("cstore", _i32), ("dy", _i32), ("hy", _i32), ("wy", _i32),
+                ("os", _i32), ("ooff", _i32 * 3), ("stats_part", _vp), ("dtype", _i32)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("x0", _vp), ("c0", _i32), ("ld0", _i32), ("x1", _vp), ("c1", _i32), ("ld1", _i32),
+                ("n", _i32), ("di", _i32), ("hi", _i32), ("wi", _i32),
+                ("g", _vp), ("cg", _i32), ("ldg", _i32),
+                ("do_", _i32), ("ho", _i32), ("wo", _i32), ("gd", _i32), ("gh", _i32), ("gw", _i32),
+                ("gs", _i32), ("goff", _i32 * 3), ("ks", _i32), ("stride", _i32), ("pad", _i32 * 3),
+                ("workspace", _vp), ("workspace_bytes", _i64),
+                ("dw", _vp), ("cout", _i32), ("cin", _i32), ("s_co", _i64), ("s_ci", _i64), ("s_k", _i64 * 3),
+                ("tbase", _i32 * 3), ("tstep", _i32 * 3), ("accumulate", _i32), ("dtype", _i32)]
+
+
+class NormActDesc(C.Structure):
+    _fields_ = [("z", _vp), ("ldz", _i32), ("a", _vp), ("lda", _i32), ("c", _i32),
+                ("rows_per_group", _i64), ("groups", _i32),
+                ("mean", _vp), ("rstd", _vp), ("gamma", _vp), ("beta", _vp),
+                ("slope", _f32), ("drop_p", _f32), ("seed", _u64), ("dtype", _i32),
+                ("da", _vp), ("ldda", _i32), ("dz", _vp), ("lddz", _i32),
+                ("part", _vp), ("blocks_per_group", _i32), ("sums", _vp), ("batch_stats", _i32)]
+
+
+_SIGNATURES = {
+    "mi355_version": (C.c_int, []),
+    "mi355_last_error": (C.c_char_p, []),
+    "mi355_pack_ncdhw": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "mi355_unpack_ncdhw": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _i32, _vp]),
+    "mi355_weight_pack": (C.c_int, [C.POINTER(WpackDesc), _vp]),
+    "mi355_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), _vp]),
+    "mi355_conv_num_tiles": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(_i32), C.POINTER(_i32)]),
+    "mi355_conv_wgrad_workspace": (_i64, [C.POINTER(WgradDesc)]),
+    "mi355_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc), _vp]),
+    "mi355_channel_stats": (C.c_int, [_vp, _i32, _i32, _i64, _i32, _vp, _i32, _i32, _vp]),
+    "mi355_channel_stats_blocks": (_i32, [_i64]),
+    "mi355_norm_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i64, _vp, _f32, _vp, _vp, _vp, _vp, _f32, _vp]),
+    "mi355_normact_fwd": (C.c_int, [C.POINTER(NormActDesc), _vp]),
+    "mi355_normact_bwd_reduce": (C.c_int, [C.POINTER(NormActDesc), _vp]),
+    "mi355_normact_bwd_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "mi355_normact_bwd_apply": (C.c_int, [C.POINTER(NormActDesc), _vp]),
+    "mi355_colsum_finalize": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "mi355_maxpool2_fwd": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mi355_maxpool2_bwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mi355_l1_blocks": (_i32, [_i64]),
+    "mi355_l1_fwd": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "mi355_l1_bwd": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "mi355_adamw_multi": (C.c_int, [_vp, _vp, _i32, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
+    "mi355_mfma_selftest": (C.c_int, [_vp, _vp, _vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lock = threading.Lock()
+_lib = None
+
+
+class Mi355Error(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes library object.  Raises if the .so is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise Mi355Error(
+                    f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in _SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().mi355_last_error().decode("utf-8", "replace")
+        raise Mi355Error(f"{what or 'mi355 call'} failed ({rc}): {msg}")

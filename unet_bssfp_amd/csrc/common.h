@@ -1,0 +1,121 @@
+// Shared device/host helpers for the gfx950 kernels.  Wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/mi355_unet.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// storage type of bf16 activations / packed weights
+struct bf16_t { uint16_t v; };
+
+// ---- error plumbing (thread-local message, no exceptions across the ABI) ----
+void mi355_set_error(const char* fmt, ...);
+int mi355_check_launch(const char* what);
+
+#define MI355_REQUIRE(cond, ...)                      \
+  do {                                                \
+    if (!(cond)) {                                    \
+      mi355_set_error(__VA_ARGS__);                   \
+      return MI355_ERR_ARG;                           \
+    }                                                 \
+  } while (0)
+
+// ---- numeric helpers ----
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+  // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, keeps NaN a NaN)
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(uint16_t, b);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int kDtype = MI355_DT_F32;
+  static constexpr int kPer16B = 4;
+  static __device__ __forceinline__ float load(const float* p) { return *p; }
+  static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int kDtype = MI355_DT_BF16;
+  static constexpr int kPer16B = 8;
+  static __device__ __forceinline__ float load(const bf16_t* p) { return bf16_bits_to_f32(p->v); }
+  static __device__ __forceinline__ void store(bf16_t* p, float v) { p->v = f32_to_bf16_bits(v); }
+};
+
+// 16 bytes of T unpacked to floats (4 for f32, 8 for bf16)
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+  static constexpr int N = 4;
+  float f[4];
+  __device__ __forceinline__ void load(const void* p) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+  }
+  __device__ __forceinline__ void store(void* p) const {
+    *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+  }
+};
+template <> struct Vec16<bf16_t> {
+  static constexpr int N = 8;
+  float f[8];
+  __device__ __forceinline__ void load(const void* p) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __uint_as_float(w[i] << 16);
+      f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  __device__ __forceinline__ void store(void* p) const {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      w[i] = (uint32_t)f32_to_bf16_bits(f[2 * i]) | ((uint32_t)f32_to_bf16_bits(f[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+// ---- MFMA operand fragments: 16 channels of one row (voxel or output channel) ----
+// f32 : two groups of 8 channels; lane half h owns channels 8g+4h .. 8g+4h+3 (one float4 each),
+//       consumed by 4 x v_mfma_f32_32x32x2_f32 per group (k = {8g+s, 8g+4+s}, s = 0..3).
+// bf16: lane half h owns channels 8h .. 8h+7 (one 16-B vector), one v_mfma_f32_32x32x16_bf16.
+template <typename T> struct Frag;
+template <> struct Frag<float> {
+  float4 g0, g1;
+  // p points at the 16-channel row; hoff = h*16 bytes already applied by the caller
+  __device__ __forceinline__ void load(const char* p) {
+    g0 = *reinterpret_cast<const float4*>(p);
+    g1 = *reinterpret_cast<const float4*>(p + 32);
+  }
+  __device__ __forceinline__ void zero() { g0 = make_float4(0, 0, 0, 0); g1 = g0; }
+};
+template <> struct Frag<bf16_t> {
+  uint4 v;
+  __device__ __forceinline__ void load(const char* p) { v = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void zero() { v = make_uint4(0, 0, 0, 0); }
+};
+
+__device__ __forceinline__ void mma16(const Frag<float>& a, const Frag<float>& b, f32x16& acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.g0.x, b.g0.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.g0.y, b.g0.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.g0.z, b.g0.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.g0.w, b.g0.w, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.g1.x, b.g1.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.g1.y, b.g1.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.g1.z, b.g1.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.g1.w, b.g1.w, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(const Frag<bf16_t>& a, const Frag<bf16_t>& b, f32x16& acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.v),
+                                                __builtin_bit_cast(bf16x8, b.v), acc, 0, 0, 0);
+}
+
+// accumulator register i of lane half h holds D[row][col = lane & 31]
+__device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

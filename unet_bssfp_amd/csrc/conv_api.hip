@@ -1,0 +1,115 @@
+// Host dispatch of the implicit-GEMM convolution kernels (C ABI: mi355_conv_fwd).
+#include "conv_kernels.h"
+
+namespace {
+
+struct Plan {
+  bool halo;
+  int shape;      // halo: 0 wide (2x4x32), 1 mid (2x8x16), 2 small (4x8x8)
+  int vt, ct;
+  int tiles_d, tiles_h, tiles_w;
+  long long tiles;
+  int tiles_per_sample;
+};
+
+const int kTD[3] = {2, 2, 4}, kTH[3] = {4, 8, 8}, kTW[3] = {32, 16, 8};
+
+int make_plan(const mi355_conv_desc* d, Plan* p) {
+  MI355_REQUIRE(d && d->x0 && d->wp && d->y, "conv: null pointer");
+  MI355_REQUIRE(d->dtype == MI355_DT_F32 || d->dtype == MI355_DT_BF16, "conv: bad dtype %d", d->dtype);
+  MI355_REQUIRE(d->c0 > 0 && d->c0 % 16 == 0 && d->c1 >= 0 && d->c1 % 16 == 0, "conv: channels must be multiples of 16 (c0=%d c1=%d)", d->c0, d->c1);
+  MI355_REQUIRE(d->c1 == 0 || d->x1, "conv: c1 > 0 without x1");
+  MI355_REQUIRE(d->ld0 >= d->c0 && (d->c1 == 0 || d->ld1 >= d->c1), "conv: ld < channels");
+  MI355_REQUIRE(d->ld0 % (d->dtype == MI355_DT_F32 ? 4 : 8) == 0 && (d->c1 == 0 || d->ld1 % (d->dtype == MI355_DT_F32 ? 4 : 8) == 0), "conv: ld must keep rows 16-byte aligned");
+  MI355_REQUIRE(d->coutp > 0 && d->coutp % 32 == 0, "conv: coutp %% 32 != 0");
+  MI355_REQUIRE(d->cstore > 0 && d->cstore <= d->coutp && d->ldy >= d->cstore, "conv: bad cstore/ldy");
+  MI355_REQUIRE(d->ks >= 1 && d->ks <= 4 && d->stride >= 1 && d->stride <= 2, "conv: unsupported ks=%d stride=%d", d->ks, d->stride);
+  MI355_REQUIRE(d->n > 0 && d->di > 0 && d->hi > 0 && d->wi > 0 && d->do_ > 0 && d->ho > 0 && d->wo > 0, "conv: empty extent");
+  MI355_REQUIRE(d->os >= 1, "conv: os < 1");
+  MI355_REQUIRE((d->do_ - 1) * d->os + d->ooff[0] < d->dy && (d->ho - 1) * d->os + d->ooff[1] < d->hy &&
+                    (d->wo - 1) * d->os + d->ooff[2] < d->wy && d->ooff[0] >= 0 && d->ooff[1] >= 0 && d->ooff[2] >= 0,
+                "conv: output grid exceeds the output tensor");
+  p->ct = (d->coutp % 64 == 0) ? 2 : 1;
+  p->halo = (d->ks == 3 && d->stride == 1);
+  if (p->halo) {
+    p->shape = d->wo > 16 ? 0 : (d->wo > 8 ? 1 : 2);
+    p->vt = 2;
+    p->tiles_d = ceil_div(d->do_, kTD[p->shape]);
+    p->tiles_h = ceil_div(d->ho, kTH[p->shape]);
+    p->tiles_w = ceil_div(d->wo, kTW[p->shape]);
+    p->tiles_per_sample = p->tiles_d * p->tiles_h * p->tiles_w;
+    p->tiles = (long long)p->tiles_per_sample * d->n;
+  } else {
+    const long long per = (long long)d->do_ * d->ho * d->wo;
+    const long long m = per * d->n;
+    p->vt = (m >= 128 * 2 * 512) ? 2 : 1;
+    const int wg = 128 * p->vt;
+    p->tiles = (m + wg - 1) / wg;
+    p->tiles_per_sample = (per % wg == 0) ? (int)(per / wg) : 0;
+    p->tiles_d = p->tiles_h = p->tiles_w = 0;
+    p->shape = 0;
+  }
+  MI355_REQUIRE(p->tiles < (1ll << 31), "conv: too many tiles");
+  return MI355_OK;
+}
+
+template <typename T>
+int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
+  ConvArgs a;
+  a.x0 = (const char*)d->x0; a.x1 = (const char*)d->x1;
+  a.c0 = d->c0; a.c1 = d->c1; a.ld0 = d->ld0; a.ld1 = d->ld1;
+  a.n = d->n; a.di = d->di; a.hi = d->hi; a.wi = d->wi;
+  a.do_ = d->do_; a.ho = d->ho; a.wo = d->wo;
+  a.ks = d->ks; a.stride = d->stride;
+  a.pd = d->pad[0]; a.ph = d->pad[1]; a.pw = d->pad[2];
+  a.wp = (const char*)d->wp; a.coutp = d->coutp; a.bias = d->bias;
+  a.y = (char*)d->y; a.ldy = d->ldy; a.cstore = d->cstore;
+  a.dy = d->dy; a.hy = d->hy; a.wy = d->wy; a.os = d->os;
+  a.od = d->ooff[0]; a.oh = d->ooff[1]; a.ow = d->ooff[2];
+  a.stats = d->stats_part;
+  a.tiles_d = p.tiles_d; a.tiles_h = p.tiles_h; a.tiles_w = p.tiles_w;
+  a.nchunks = (d->c0 + d->c1) / 16;
+  a.m_total = (long long)d->n * d->do_ * d->ho * d->wo;
+  dim3 grid((unsigned)p.tiles, (unsigned)(d->coutp / (32 * p.ct)));
+  dim3 block(256);
+#define HALO(TD, TH, TW, CT)                                     \
+  do {                                                           \
+    constexpr int lds = conv_k3_halo_lds<T, TD, TH, TW>();       \
+    conv_k3_halo_kernel<T, TD, TH, TW, CT><<<grid, block, lds, st>>>(a); \
+  } while (0)
+  if (p.halo) {
+    if (p.shape == 0) { if (p.ct == 2) HALO(2, 4, 32, 2); else HALO(2, 4, 32, 1); }
+    else if (p.shape == 1) { if (p.ct == 2) HALO(2, 8, 16, 2); else HALO(2, 8, 16, 1); }
+    else { if (p.ct == 2) HALO(4, 8, 8, 2); else HALO(4, 8, 8, 1); }
+  } else {
+    if (p.vt == 2) {
+      if (p.ct == 2) conv_gather_kernel<T, 2, 2><<<grid, block, 0, st>>>(a);
+      else conv_gather_kernel<T, 2, 1><<<grid, block, 0, st>>>(a);
+    } else {
+      if (p.ct == 2) conv_gather_kernel<T, 1, 2><<<grid, block, 0, st>>>(a);
+      else conv_gather_kernel<T, 1, 1><<<grid, block, 0, st>>>(a);
+    }
+  }
+#undef HALO
+  return mi355_check_launch("conv_fwd");
+}
+
+}  // namespace
+
+extern "C" int mi355_conv_num_tiles(const mi355_conv_desc* d, int32_t* tiles, int32_t* tiles_per_sample) {
+  Plan p;
+  int rc = make_plan(d, &p);
+  if (rc) return rc;
+  if (tiles) *tiles = (int32_t)p.tiles;
+  if (tiles_per_sample) *tiles_per_sample = p.tiles_per_sample;
+  return MI355_OK;
+}
+
+extern "C" int mi355_conv_fwd(const mi355_conv_desc* d, void* stream) {
+  Plan p;
+  int rc = make_plan(d, &p);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == MI355_DT_F32) return launch<float>(d, p, st);
+  return launch<bf16_t>(d, p, st);
+}

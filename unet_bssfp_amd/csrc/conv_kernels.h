@@ -1,0 +1,220 @@
+// Implicit-GEMM convolution kernels (NDHWC, MFMA 32x32, 64-lane waves, 4 waves per workgroup).
+//
+// GEMM view: D[voxel][cout] += A[voxel][k] * B[k][cout], k = (tap, cin).  A = activations
+// (MFMA rows = 32 voxels of a subtile), B = packed weights (MFMA cols = 32 output channels), so
+// each lane ends up with ONE output channel and 16 voxels: channel statistics are lane-local
+// sums and every store instruction writes two full 128-B (f32) channel rows.
+//
+//  conv_k3_halo_kernel : 3x3x3 stride-1 (U-Net convs and their data gradients, ~88 % of the FLOPs).
+//      The workgroup stages the (TD+2)x(TH+2)x(TW+2) halo of a 16-channel chunk in LDS once and
+//      re-reads it 27 times (LDS 256 B/clk/CU instead of L1 64 B/clk/CU); the next chunk's halo
+//      is prefetched into registers while the MFMAs run.
+//  conv_gather_kernel  : any cubic kernel / stride / padding (PatchGAN k4s2, transposed-conv
+//      parity classes, 1x1x1): A fragments are gathered straight from global memory.
+#pragma once
+#include "conv_common.h"
+
+template <typename T, int TD, int TH, int TW, int CT>
+__global__ __launch_bounds__(256) void conv_k3_halo_kernel(const ConvArgs a) {
+  constexpr int ES = sizeof(T);
+  constexpr int RS = 32 / TW;                 // rows (h) per 32-voxel subtile
+  constexpr int SPD = TH / RS;                // subtiles per d-slice
+  constexpr int NSUB = TD * SPD;
+  constexpr int VT = NSUB / 4;
+  static_assert(NSUB % 4 == 0 && TW * RS == 32 && TH % RS == 0, "tile shape");
+  constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
+  constexpr int VS = 16 * ES + 16;            // LDS bytes per halo voxel (+16: bank spread)
+  constexpr int PPV = ES;                     // 16-B pieces per voxel (16 ch * ES / 16)
+  constexpr int NPIECE = HD * HH * HW * PPV;
+  constexpr int NP = (NPIECE + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+
+  int t = blockIdx.x;
+  const int tw_i = t % a.tiles_w; t /= a.tiles_w;
+  const int th_i = t % a.tiles_h; t /= a.tiles_h;
+  const int td_i = t % a.tiles_d;
+  const int n = t / a.tiles_d;
+  const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
+  const int co_base = blockIdx.y * (32 * CT);
+
+  // ---- staging plan: which input voxel each of this thread's 16-B pieces comes from ----
+  int gvox[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int p = tid + i * 256;
+    const int vox = p / PPV;
+    const int hw = vox % HW, hh = (vox / HW) % HH, hd = vox / (HW * HH);
+    const int gd = d0 + hd - a.pd, gh = h0 + hh - a.ph, gw = w0 + hw - a.pw;
+    const bool ok = p < NPIECE && gd >= 0 && gd < a.di && gh >= 0 && gh < a.hi && gw >= 0 && gw < a.wi;
+    gvox[i] = ok ? ((n * a.di + gd) * a.hi + gh) * a.wi + gw : -1;
+  }
+  uint4 stage[NP];
+  auto load_chunk = [&](int c) {
+    const int cb = c * 16;
+    const bool first = cb < a.c0;
+    const char* src = first ? a.x0 : a.x1;
+    const long long ld = first ? a.ld0 : a.ld1;
+    const int cbase = first ? cb : cb - a.c0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int part = (tid + i * 256) % PPV;
+      if (gvox[i] >= 0)
+        stage[i] = *reinterpret_cast<const uint4*>(src + ((long long)gvox[i] * ld + cbase) * ES + part * 16);
+      else
+        stage[i] = make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = tid + i * 256;
+      if (p < NPIECE) *reinterpret_cast<uint4*>(smem + (p / PPV) * VS + (p % PPV) * 16) = stage[i];
+    }
+  };
+
+  // ---- per-lane LDS base of each subtile's A fragment ----
+  int lbase[VT];
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt) {
+    const int s = wave * VT + vt;
+    const int sd = s / SPD, sh = (s % SPD) * RS;
+    lbase[vt] = ((sd * HH + sh + r / TW) * HW + (r % TW)) * VS + h * 16;
+  }
+  const char* wlane = a.wp + ((long long)co_base + r) * (16 * ES) + h * 16;
+  const long long wtap = (long long)a.coutp * (16 * ES);   // bytes per (chunk, tap)
+
+  f32x16 acc[VT][CT];
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[vt][ct][i] = 0.f;
+
+  load_chunk(0);
+  for (int c = 0; c < a.nchunks; ++c) {
+    __syncthreads();                 // previous chunk's LDS reads are done
+    store_chunk();
+    __syncthreads();
+    if (c + 1 < a.nchunks) load_chunk(c + 1);   // in flight under the MFMAs
+    const char* wc = wlane + (long long)c * 27 * wtap;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int tap = (kd * 3 + kh) * 3 + kw;
+          const int toff = ((kd * HH + kh) * HW + kw) * VS;
+          Frag<T> b[CT];
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) b[ct].load(wc + tap * wtap + ct * (32 * 16 * ES));
+#pragma unroll
+          for (int vt = 0; vt < VT; ++vt) {
+            Frag<T> af;
+            af.load(smem + lbase[vt] + toff);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) mma16(af, b[ct], acc[vt][ct]);
+          }
+        }
+  }
+
+  // ---- epilogue ----
+  long long yoff[VT];
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt) {
+    const int s = wave * VT + vt;
+    const int gd = d0 + s / SPD, gh = h0 + (s % SPD) * RS + r / TW, gw = w0 + r % TW;
+    const bool ok = gd < a.do_ && gh < a.ho && gw < a.wo;
+    yoff[vt] = ok ? ((((long long)n * a.dy + (gd * a.os + a.od)) * a.hy + (gh * a.os + a.oh)) * a.wy +
+                     (gw * a.os + a.ow)) * a.ldy
+                  : -1;
+  }
+  conv_epilogue<T, VT, CT>(a, acc, yoff, co_base, blockIdx.x, reinterpret_cast<float*>(smem));
+}
+
+template <typename T, int TD, int TH, int TW>
+constexpr int conv_k3_halo_lds() {
+  // staging halo, or the 4*CT*64 floats of the statistics reduction (always smaller)
+  return (TD + 2) * (TH + 2) * (TW + 2) * (16 * (int)sizeof(T) + 16);
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename T, int VT, int CT>
+__global__ __launch_bounds__(256) void conv_gather_kernel(const ConvArgs a) {
+  constexpr int ES = sizeof(T);
+  __shared__ float red[4 * CT * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int co_base = blockIdx.y * (32 * CT);
+
+  // this lane's voxel (MFMA row r) in each subtile
+  int vn[VT], vd[VT], vh[VT], vw[VT];
+  bool vok[VT];
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt) {
+    long long m = (long long)blockIdx.x * (128 * VT) + (wave * VT + vt) * 32 + r;
+    vok[vt] = m < a.m_total;
+    if (!vok[vt]) m = 0;
+    vw[vt] = (int)(m % a.wo); m /= a.wo;
+    vh[vt] = (int)(m % a.ho); m /= a.ho;
+    vd[vt] = (int)(m % a.do_);
+    vn[vt] = (int)(m / a.do_);
+  }
+  const char* wlane = a.wp + ((long long)co_base + r) * (16 * ES) + h * 16;
+  const long long wtap = (long long)a.coutp * (16 * ES);
+  const int ntaps = a.ks * a.ks * a.ks;
+
+  f32x16 acc[VT][CT];
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[vt][ct][i] = 0.f;
+
+  int kd = 0, kh = 0, kw = 0;
+  for (int tap = 0; tap < ntaps; ++tap) {
+    long long vox[VT];
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt) {
+      const int id = vd[vt] * a.stride + kd - a.pd;
+      const int ih = vh[vt] * a.stride + kh - a.ph;
+      const int iw = vw[vt] * a.stride + kw - a.pw;
+      const bool ok = vok[vt] && id >= 0 && id < a.di && ih >= 0 && ih < a.hi && iw >= 0 && iw < a.wi;
+      vox[vt] = ok ? (((long long)vn[vt] * a.di + id) * a.hi + ih) * a.wi + iw : -1;
+    }
+    for (int c = 0; c < a.nchunks; ++c) {
+      const int cb = c * 16;
+      const bool first = cb < a.c0;
+      const char* src = first ? a.x0 : a.x1;
+      const long long ld = first ? a.ld0 : a.ld1;
+      const int cbase = first ? cb : cb - a.c0;
+      const char* wc = wlane + ((long long)c * ntaps + tap) * wtap;
+      Frag<T> b[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) b[ct].load(wc + ct * (32 * 16 * ES));
+#pragma unroll
+      for (int vt = 0; vt < VT; ++vt) {
+        Frag<T> af;
+        if (vox[vt] >= 0) af.load(src + (vox[vt] * ld + cbase) * ES + h * 16);
+        else af.zero();
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) mma16(af, b[ct], acc[vt][ct]);
+      }
+    }
+    if (++kw == a.ks) { kw = 0; if (++kh == a.ks) { kh = 0; ++kd; } }
+  }
+
+  long long yoff[VT];
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt) {
+    yoff[vt] = vok[vt] ? ((((long long)vn[vt] * a.dy + (vd[vt] * a.os + a.od)) * a.hy +
+                           (vh[vt] * a.os + a.oh)) * a.wy + (vw[vt] * a.os + a.ow)) * a.ldy
+                       : -1;
+  }
+  conv_epilogue<T, VT, CT>(a, acc, yoff, co_base, blockIdx.x, red);
+}

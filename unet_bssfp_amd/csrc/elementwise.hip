@@ -1,0 +1,741 @@
+// HBM-bound kernels of the path: layout pack/unpack, weight packing, channel statistics,
+// fused norm + dropout + LeakyReLU (forward / backward), max-pool, L1 loss, multi-tensor AdamW.
+// NDHWC rows are read and written as 16-byte vectors per lane (coalesced along channels).
+#include "common.h"
+
+namespace {
+
+constexpr int kRowsPerStatBlock = 2048;
+
+// ------------------------------------------------------------------ pack / unpack
+template <typename T>
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src, T* __restrict__ dst, int c,
+                                                    long long v, int ld, int coff, int zero_to) {
+  constexpr int EPV = Elem<T>::kPer16B;
+  const long long vox = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y;
+  if (vox >= v) return;
+  const float* s = src + (long long)n * c * v + vox;
+  T* drow = dst + ((long long)n * v + vox) * ld;
+  for (int e0 = coff; e0 < zero_to; e0 += EPV) {
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+      const int ch = e0 + j - coff;
+      o.f[j] = ch < c ? s[(long long)ch * v] : 0.f;
+    }
+    o.store(drow + e0);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void unpack_kernel(const T* __restrict__ src, float* __restrict__ dst, int c,
+                                                      long long v, int ld, int coff) {
+  const long long vox = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y;
+  if (vox >= v) return;
+  const T* srow = src + ((long long)n * v + vox) * ld + coff;
+  float* d = dst + (long long)n * c * v + vox;
+  for (int ch = 0; ch < c; ++ch) d[(long long)ch * v] = Elem<T>::load(srow + ch);
+}
+
+// ------------------------------------------------------------------ weight pack
+struct WpackArgs {
+  const float* src; void* dst;
+  int cout, cin, coutp, cinp, ks;
+  long long s_co, s_ci, s_k0, s_k1, s_k2;
+  int tb0, tb1, tb2, ts0, ts1, ts2;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void wpack_kernel(const WpackArgs a) {
+  const int ntaps = a.ks * a.ks * a.ks;
+  const long long total = (long long)(a.cinp / 16) * ntaps * a.coutp * 16;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int e = (int)(idx % 16);
+  const int co = (int)((idx / 16) % a.coutp);
+  const int tap = (int)((idx / (16ll * a.coutp)) % ntaps);
+  const int chunk = (int)(idx / (16ll * a.coutp * ntaps));
+  const int ci = chunk * 16 + e;
+  float v = 0.f;
+  if (co < a.cout && ci < a.cin) {
+    const int td = tap / (a.ks * a.ks), th = (tap / a.ks) % a.ks, tw = tap % a.ks;
+    v = a.src[co * a.s_co + ci * a.s_ci + (a.tb0 + a.ts0 * td) * a.s_k0 + (a.tb1 + a.ts1 * th) * a.s_k1 +
+              (a.tb2 + a.ts2 * tw) * a.s_k2];
+  }
+  Elem<T>::store(reinterpret_cast<T*>(a.dst) + idx, v);
+}
+
+// ------------------------------------------------------------------ channel statistics
+// One block = up to kRowsPerStatBlock rows of one group.  Thread = (row-in-pass, 16-B piece).
+// f(row values) is supplied by the functor; sums of two quantities per channel are produced.
+template <typename T, typename F>
+__device__ __forceinline__ void block_channel_sums(int c, long long row_begin, long long row_end, F f,
+                                                   float* out0, float* out1) {
+  constexpr int EPV = Elem<T>::kPer16B;
+  __shared__ float red[256 * 16];
+  const int lpr = c / EPV;                 // 16-B pieces per row (<= 128)
+  const int rpp = 256 / lpr;               // rows per pass
+  const int piece = threadIdx.x % lpr, rsub = threadIdx.x / lpr;
+  float s0[EPV], s1[EPV];
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+  if (rsub < rpp)
+    for (long long row = row_begin + rsub; row < row_end; row += rpp) f(row, piece * EPV, s0, s1);
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) {
+    red[threadIdx.x * 16 + j] = s0[j];
+    red[threadIdx.x * 16 + 8 + j] = s1[j];
+  }
+  __syncthreads();
+  for (int ch = threadIdx.x; ch < c; ch += 256) {
+    const int p = ch / EPV, j = ch % EPV;
+    float t0 = 0.f, t1 = 0.f;
+    for (int q = 0; q < rpp; ++q) {
+      t0 += red[(q * lpr + p) * 16 + j];
+      t1 += red[(q * lpr + p) * 16 + 8 + j];
+    }
+    out0[ch] = t0;
+    out1[ch] = t1;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict__ x, int ld, int c,
+                                                             long long rows_per_group, float* __restrict__ part,
+                                                             int blocks_per_group) {
+  const int g = blockIdx.y, b = blockIdx.x;
+  const long long rb = (rows_per_group + blocks_per_group - 1) / blocks_per_group;
+  const long long r0 = (long long)b * rb;
+  long long r1 = r0 + rb;
+  if (r1 > rows_per_group) r1 = rows_per_group;
+  const T* base = x + (long long)g * rows_per_group * ld;
+  float* out = part + ((long long)g * blocks_per_group + b) * 2 * c;
+  block_channel_sums<T>(c, r0, r1,
+      [&](long long row, int ch0, float* s0, float* s1) {
+        Vec16<T> v;
+        v.load(base + row * ld + ch0);
+#pragma unroll
+        for (int j = 0; j < Vec16<T>::N; ++j) { s0[j] += v.f[j]; s1[j] += v.f[j] * v.f[j]; }
+      },
+      out, out + c);
+}
+
+__global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restrict__ part, int ppg, int c,
+                                                            long long count, const float* __restrict__ shift,
+                                                            float eps, float* __restrict__ mean,
+                                                            float* __restrict__ rstd, float* running_mean,
+                                                            float* running_var, float momentum) {
+  const int g = blockIdx.y;
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= c) return;
+  double s1 = 0.0, s2 = 0.0;
+  const float* p = part + (long long)g * ppg * 2 * c;
+  for (int k = 0; k < ppg; ++k) {
+    s1 += (double)p[(long long)k * 2 * c + ch];
+    s2 += (double)p[(long long)k * 2 * c + c + ch];
+  }
+  const double m = s1 / (double)count;
+  double var = s2 / (double)count - m * m;
+  if (var < 0.0) var = 0.0;
+  const double mu = m + (shift ? (double)shift[ch] : 0.0);
+  mean[(long long)g * c + ch] = (float)mu;
+  rstd[(long long)g * c + ch] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unb = count > 1 ? var * (double)count / (double)(count - 1) : var;
+    running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mu);
+    running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int parts, int c,
+                                                              float* __restrict__ out) {
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= c) return;
+  double s = 0.0;
+  for (int k = 0; k < parts; ++k) s += (double)part[(long long)k * 2 * c + ch];
+  out[ch] = (float)s;
+}
+
+// ------------------------------------------------------------------ norm + dropout + LeakyReLU
+// keep-mask of element `idx` (logical index, independent of ld): 16 bits of a 32-bit mix
+__device__ __forceinline__ bool drop_keep(unsigned long long seed, unsigned long long idx, unsigned thr16) {
+  const unsigned long long pair = idx >> 1;
+  unsigned x = (unsigned)pair ^ (unsigned)(pair >> 32) * 0x9E3779B9u ^ (unsigned)seed;
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  x += (unsigned)(seed >> 32);
+  x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12;
+  const unsigned bits = (idx & 1) ? (x >> 16) : (x & 0xffffu);
+  return bits >= thr16;
+}
+
+struct NormActArgs {
+  const char* z; int ldz; char* a; int lda;
+  int c; long long rows_per_group; int groups;
+  const float* mean; const float* rstd; const float* gamma; const float* beta;
+  float slope; float drop_scale; unsigned thr16; unsigned long long seed;
+  const char* da; int ldda; char* dz; int lddz;
+  float* part; int blocks_per_group; const float* sums; int batch_stats;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void normact_fwd_kernel(const NormActArgs q) {
+  constexpr int EPV = Elem<T>::kPer16B;
+  const int g = blockIdx.y;
+  const int lpr = q.c / EPV, rpp = 256 / lpr;
+  const int piece = threadIdx.x % lpr, rsub = threadIdx.x / lpr;
+  if (rsub >= rpp) return;
+  const int ch0 = piece * EPV;
+  float sc[EPV], sh[EPV];
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) {
+    const int ch = ch0 + j;
+    const float ga = q.gamma ? q.gamma[ch] : 1.f, be = q.beta ? q.beta[ch] : 0.f;
+    if (q.mean) {
+      const float rs = q.rstd[(long long)g * q.c + ch], mu = q.mean[(long long)g * q.c + ch];
+      sc[j] = ga * rs;
+      sh[j] = be - mu * ga * rs;
+    } else { sc[j] = ga; sh[j] = be; }
+  }
+  const T* zb = reinterpret_cast<const T*>(q.z) + (long long)g * q.rows_per_group * q.ldz;
+  T* ab = reinterpret_cast<T*>(q.a) + (long long)g * q.rows_per_group * q.lda;
+  const long long stride = (long long)gridDim.x * rpp;
+  for (long long row = (long long)blockIdx.x * rpp + rsub; row < q.rows_per_group; row += stride) {
+    Vec16<T> v;
+    v.load(zb + row * q.ldz + ch0);
+    const unsigned long long e0 = ((unsigned long long)g * q.rows_per_group + row) * q.c + ch0;
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+      float t = v.f[j] * sc[j] + sh[j];
+      if (q.thr16) t = drop_keep(q.seed, e0 + j, q.thr16) ? t * q.drop_scale : 0.f;
+      v.f[j] = t > 0.f ? t : t * q.slope;
+    }
+    v.store(ab + row * q.lda + ch0);
+  }
+}
+
+// per-thread channel constants of the backward kernels
+template <int EPV> struct BwdConst { float mu[EPV], rs[EPV], ga[EPV], be[EPV]; };
+template <int EPV>
+__device__ __forceinline__ void load_bwd_const(const NormActArgs& q, int g, int ch0, BwdConst<EPV>& k) {
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) {
+    const int ch = ch0 + j;
+    k.mu[j] = q.mean ? q.mean[(long long)g * q.c + ch] : 0.f;
+    k.rs[j] = q.mean ? q.rstd[(long long)g * q.c + ch] : 1.f;
+    k.ga[j] = q.gamma ? q.gamma[ch] : 1.f;
+    k.be[j] = q.beta ? q.beta[ch] : 0.f;
+  }
+}
+// g = da * dropout * lrelu'(pre);  xhat = (z - mean) * rstd  (xhat = z when there is no norm)
+__device__ __forceinline__ void bwd_elem(const NormActArgs& q, float mu, float rs, float ga, float be, float zv,
+                                         float dav, unsigned long long eidx, float& gout, float& xhat) {
+  xhat = (zv - mu) * rs;
+  float pre = xhat * ga + be;
+  float gv = dav;
+  if (q.thr16) {
+    const bool keep = drop_keep(q.seed, eidx, q.thr16);
+    pre = keep ? pre : 0.f;
+    gv = keep ? gv * q.drop_scale : 0.f;
+  }
+  gout = pre > 0.f ? gv : gv * q.slope;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void normact_bwd_reduce_kernel(const NormActArgs q) {
+  constexpr int EPV = Elem<T>::kPer16B;
+  const int g = blockIdx.y, b = blockIdx.x;
+  const long long rb = (q.rows_per_group + q.blocks_per_group - 1) / q.blocks_per_group;
+  const long long r0 = (long long)b * rb;
+  long long r1 = r0 + rb;
+  if (r1 > q.rows_per_group) r1 = q.rows_per_group;
+  const T* zb = reinterpret_cast<const T*>(q.z) + (long long)g * q.rows_per_group * q.ldz;
+  const T* db = reinterpret_cast<const T*>(q.da) + (long long)g * q.rows_per_group * q.ldda;
+  float* out = q.part + ((long long)g * q.blocks_per_group + b) * 2 * q.c;
+  BwdConst<EPV> k;
+  load_bwd_const<EPV>(q, g, (int)(threadIdx.x % (q.c / EPV)) * EPV, k);
+  block_channel_sums<T>(q.c, r0, r1,
+      [&](long long row, int ch0, float* s0, float* s1) {
+        Vec16<T> zv, dv;
+        zv.load(zb + row * q.ldz + ch0);
+        dv.load(db + row * q.ldda + ch0);
+        const unsigned long long e0 = ((unsigned long long)g * q.rows_per_group + row) * q.c + ch0;
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+          float gv, xh;
+          bwd_elem(q, k.mu[j], k.rs[j], k.ga[j], k.be[j], zv.f[j], dv.f[j], e0 + j, gv, xh);
+          s0[j] += gv;
+          s1[j] += gv * xh;
+        }
+      },
+      out, out + q.c);
+}
+
+__global__ __launch_bounds__(256) void normact_bwd_finalize_kernel(const float* __restrict__ part, int bpg,
+                                                                   int groups, int c, float* __restrict__ sums,
+                                                                   float* dgamma, float* dbeta) {
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= c) return;
+  double tg = 0.0, tb = 0.0;
+  for (int g = 0; g < groups; ++g) {
+    double s0 = 0.0, s1 = 0.0;
+    const float* p = part + (long long)g * bpg * 2 * c;
+    for (int k = 0; k < bpg; ++k) {
+      s0 += (double)p[(long long)k * 2 * c + ch];
+      s1 += (double)p[(long long)k * 2 * c + c + ch];
+    }
+    sums[((long long)g * 2 + 0) * c + ch] = (float)s0;
+    sums[((long long)g * 2 + 1) * c + ch] = (float)s1;
+    tb += s0;
+    tg += s1;
+  }
+  if (dgamma) dgamma[ch] = (float)tg;
+  if (dbeta) dbeta[ch] = (float)tb;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void normact_bwd_apply_kernel(const NormActArgs q) {
+  constexpr int EPV = Elem<T>::kPer16B;
+  const int g = blockIdx.y;
+  const int lpr = q.c / EPV, rpp = 256 / lpr;
+  const int piece = threadIdx.x % lpr, rsub = threadIdx.x / lpr;
+  if (rsub >= rpp) return;
+  const int ch0 = piece * EPV;
+  const float inv = 1.f / (float)q.rows_per_group;
+  BwdConst<EPV> k;
+  load_bwd_const<EPV>(q, g, ch0, k);
+  float kk[EPV], m0[EPV], m1[EPV];
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) {
+    const int ch = ch0 + j;
+    kk[j] = k.ga[j] * k.rs[j];
+    const bool sub = q.mean && q.batch_stats;
+    m0[j] = sub ? q.sums[((long long)g * 2 + 0) * q.c + ch] * inv : 0.f;
+    m1[j] = sub ? q.sums[((long long)g * 2 + 1) * q.c + ch] * inv : 0.f;
+  }
+  const T* zb = reinterpret_cast<const T*>(q.z) + (long long)g * q.rows_per_group * q.ldz;
+  const T* db = reinterpret_cast<const T*>(q.da) + (long long)g * q.rows_per_group * q.ldda;
+  T* ob = reinterpret_cast<T*>(q.dz) + (long long)g * q.rows_per_group * q.lddz;
+  const long long stride = (long long)gridDim.x * rpp;
+  for (long long row = (long long)blockIdx.x * rpp + rsub; row < q.rows_per_group; row += stride) {
+    Vec16<T> zv, dv;
+    zv.load(zb + row * q.ldz + ch0);
+    dv.load(db + row * q.ldda + ch0);
+    const unsigned long long e0 = ((unsigned long long)g * q.rows_per_group + row) * q.c + ch0;
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+      float gv, xh;
+      bwd_elem(q, k.mu[j], k.rs[j], k.ga[j], k.be[j], zv.f[j], dv.f[j], e0 + j, gv, xh);
+      zv.f[j] = kk[j] * (gv - m0[j] - xh * m1[j]);
+    }
+    zv.store(ob + row * q.lddz + ch0);
+  }
+}
+
+// ------------------------------------------------------------------ max-pool 2x2x2
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y,
+                                                           int ldy, int c, int d, int h, int w, long long total) {
+  constexpr int EPV = Elem<T>::kPer16B;
+  const int lpr = c / EPV;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int piece = (int)(idx % lpr);
+  long long o = idx / lpr;
+  const int od_ = d / 2, oh_ = h / 2, ow_ = w / 2;
+  const int ow = (int)(o % ow_); long long t = o / ow_;
+  const int oh = (int)(t % oh_); t /= oh_;
+  const int od = (int)(t % od_); const int n = (int)(t / od_);
+  Vec16<T> m;
+  bool firstv = true;
+#pragma unroll
+  for (int kd = 0; kd < 2; ++kd)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 2; ++kw) {
+        const long long vox = (((long long)n * d + 2 * od + kd) * h + 2 * oh + kh) * w + 2 * ow + kw;
+        Vec16<T> v;
+        v.load(x + vox * ldx + piece * EPV);
+        if (firstv) { m = v; firstv = false; }
+        else {
+#pragma unroll
+          for (int j = 0; j < EPV; ++j) m.f[j] = (v.f[j] > m.f[j] || v.f[j] != v.f[j]) ? v.f[j] : m.f[j];
+        }
+      }
+  m.store(y + o * ldy + piece * EPV);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ y,
+                                                           int ldy, const T* __restrict__ dy, int lddy,
+                                                           T* __restrict__ dx, int lddx, int c, int d, int h, int w,
+                                                           long long total) {
+  constexpr int EPV = Elem<T>::kPer16B;
+  const int lpr = c / EPV;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int piece = (int)(idx % lpr);
+  long long o = idx / lpr;
+  const int od_ = d / 2, oh_ = h / 2, ow_ = w / 2;
+  const int ow = (int)(o % ow_); long long t = o / ow_;
+  const int oh = (int)(t % oh_); t /= oh_;
+  const int od = (int)(t % od_); const int n = (int)(t / od_);
+  Vec16<T> m, g;
+  m.load(y + o * ldy + piece * EPV);
+  g.load(dy + o * lddy + piece * EPV);
+  bool taken[EPV];
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) taken[j] = false;
+#pragma unroll
+  for (int kd = 0; kd < 2; ++kd)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 2; ++kw) {
+        const long long vox = (((long long)n * d + 2 * od + kd) * h + 2 * oh + kh) * w + 2 * ow + kw;
+        Vec16<T> v, outv;
+        v.load(x + vox * ldx + piece * EPV);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+          const bool hit = !taken[j] && (v.f[j] == m.f[j] || v.f[j] != v.f[j]);
+          outv.f[j] = hit ? g.f[j] : 0.f;
+          taken[j] = taken[j] || hit;
+        }
+        outv.store(dx + vox * lddx + piece * EPV);
+      }
+}
+
+// ------------------------------------------------------------------ L1 loss
+constexpr int kL1PerBlock = 256 * 16;
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         long long count, float* __restrict__ partials) {
+  __shared__ float red[256];
+  const long long base = (long long)blockIdx.x * kL1PerBlock;
+  float s = 0.f;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const long long idx = base + i * 256 + threadIdx.x;
+    if (idx < count) s += fabsf(a[idx] - b[idx]);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void l1_final_kernel(const float* __restrict__ partials, int n, long long count,
+                                                       float* out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)partials[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)(red[0] / (double)count);
+}
+__global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                     long long count, const float* __restrict__ gscale,
+                                                     float* __restrict__ da) {
+  const float k = gscale[0] / (float)count;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+    const float dlt = a[i] - b[i];
+    da[i] = dlt > 0.f ? k : (dlt < 0.f ? -k : 0.f);
+  }
+}
+
+// ------------------------------------------------------------------ AdamW (multi-tensor)
+__global__ __launch_bounds__(256) void adamw_kernel(const void* const* __restrict__ ptrs,
+                                                    const long long* __restrict__ sizes, float lr, float beta1,
+                                                    float beta2, float eps, float wd, float bc1, float rsqrt_bc2) {
+  const int t = blockIdx.y;
+  const long long nel = sizes[t];
+  float* p = (float*)ptrs[4 * t];
+  const float* g = (const float*)ptrs[4 * t + 1];
+  float* m = (float*)ptrs[4 * t + 2];
+  float* v = (float*)ptrs[4 * t + 3];
+  const float step_size = lr / bc1;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nel; i += stride) {
+    const float gi = g[i];
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
+    pi -= step_size * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+
+// ------------------------------------------------------------------ MFMA layout probe
+__global__ void mfma_selftest_kernel(float* out_f32, float* out_bf16) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 31, h = lane >> 5;
+  // A[i][k] = i + 1 (k = 0 only), B[k][j] = 100 * (j + 1) (k = 0 only)  =>  D[i][j] = (i+1)*100*(j+1)
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h == 0 ? (float)(r + 1) : 0.f, h == 0 ? 100.f * (r + 1) : 0.f, acc, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) out_f32[acc_row(i, h) * 32 + r] = acc[i];
+  // bf16: A[i][k] = (i+1) at k == 3, B[k][j] = (j+1) at k == 3 (k = 8h + e -> h = 0, e = 3), plus
+  // A[i][k=12] = 1, B[12][j] = 0.5 (h = 1, e = 4)  =>  D[i][j] = (i+1)(j+1) + 0.5
+  Frag<bf16_t> fa, fb;
+  uint16_t ea[8] = {0, 0, 0, 0, 0, 0, 0, 0}, eb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (h == 0) { ea[3] = f32_to_bf16_bits((float)(r + 1)); eb[3] = f32_to_bf16_bits((float)(r + 1)); }
+  else { ea[4] = f32_to_bf16_bits(1.f); eb[4] = f32_to_bf16_bits(0.5f); }
+  fa.v = make_uint4(ea[0] | (ea[1] << 16), ea[2] | (ea[3] << 16), ea[4] | (ea[5] << 16), ea[6] | (ea[7] << 16));
+  fb.v = make_uint4(eb[0] | (eb[1] << 16), eb[2] | (eb[3] << 16), eb[4] | (eb[5] << 16), eb[6] | (eb[7] << 16));
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  mma16(fa, fb, acc);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) out_bf16[acc_row(i, h) * 32 + r] = acc[i];
+}
+
+template <typename T> const T* cp(const void* p) { return reinterpret_cast<const T*>(p); }
+template <typename T> T* mp(void* p) { return reinterpret_cast<T*>(p); }
+
+int check_rows(int c, int ld, int dtype, const char* who) {
+  const int epv = dtype == MI355_DT_F32 ? 4 : 8;
+  MI355_REQUIRE(dtype == MI355_DT_F32 || dtype == MI355_DT_BF16, "%s: bad dtype", who);
+  MI355_REQUIRE(c > 0 && c % 16 == 0 && c <= 1024, "%s: channels must be a multiple of 16 and <= 1024 (c=%d)", who, c);
+  MI355_REQUIRE(ld >= c && ld % epv == 0, "%s: ld=%d must be >= c and keep rows 16-byte aligned", who, ld);
+  MI355_REQUIRE(c / epv <= 256, "%s: too many channels", who);
+  return MI355_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355_pack_ncdhw(const float* src, void* dst, int32_t n, int32_t c, int64_t v, int32_t ld, int32_t coff,
+                     int32_t zero_to, int32_t dtype, void* stream) {
+  MI355_REQUIRE(src && dst && n > 0 && c > 0 && v > 0, "pack: bad argument");
+  const int epv = dtype == MI355_DT_F32 ? 4 : 8;
+  MI355_REQUIRE(dtype == MI355_DT_F32 || dtype == MI355_DT_BF16, "pack: bad dtype");
+  MI355_REQUIRE(coff % epv == 0 && zero_to <= ld && (zero_to - coff) % epv == 0 && zero_to - coff >= c && ld % epv == 0,
+                "pack: channel window [%d,%d) of ld %d must be 16-byte aligned and hold c=%d", coff, zero_to, ld, c);
+  dim3 grid((unsigned)((v + 255) / 256), n);
+  if (dtype == MI355_DT_F32)
+    hipLaunchKernelGGL(pack_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, c, (long long)v, ld, coff, zero_to);
+  else
+    hipLaunchKernelGGL(pack_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, c, (long long)v, ld, coff, zero_to);
+  return mi355_check_launch("pack");
+}
+
+int mi355_unpack_ncdhw(const void* src, float* dst, int32_t n, int32_t c, int64_t v, int32_t ld, int32_t coff,
+                       int32_t dtype, void* stream) {
+  MI355_REQUIRE(src && dst && n > 0 && c > 0 && v > 0 && coff >= 0 && coff + c <= ld, "unpack: bad argument");
+  MI355_REQUIRE(dtype == MI355_DT_F32 || dtype == MI355_DT_BF16, "unpack: bad dtype");
+  dim3 grid((unsigned)((v + 255) / 256), n);
+  if (dtype == MI355_DT_F32)
+    hipLaunchKernelGGL(unpack_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, dst, c, (long long)v, ld, coff);
+  else
+    hipLaunchKernelGGL(unpack_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, c, (long long)v, ld, coff);
+  return mi355_check_launch("unpack");
+}
+
+int mi355_weight_pack(const mi355_wpack_desc* d, void* stream) {
+  MI355_REQUIRE(d && d->src && d->dst, "weight_pack: null pointer");
+  MI355_REQUIRE(d->coutp % 32 == 0 && d->cinp % 16 == 0 && d->cout <= d->coutp && d->cin <= d->cinp && d->ks >= 1 && d->ks <= 4,
+                "weight_pack: bad extents");
+  MI355_REQUIRE(d->dtype == MI355_DT_F32 || d->dtype == MI355_DT_BF16, "weight_pack: bad dtype");
+  WpackArgs a;
+  a.src = d->src; a.dst = d->dst; a.cout = d->cout; a.cin = d->cin; a.coutp = d->coutp; a.cinp = d->cinp; a.ks = d->ks;
+  a.s_co = d->s_co; a.s_ci = d->s_ci; a.s_k0 = d->s_k[0]; a.s_k1 = d->s_k[1]; a.s_k2 = d->s_k[2];
+  a.tb0 = d->tbase[0]; a.tb1 = d->tbase[1]; a.tb2 = d->tbase[2];
+  a.ts0 = d->tstep[0]; a.ts1 = d->tstep[1]; a.ts2 = d->tstep[2];
+  const long long total = (long long)d->cinp * d->ks * d->ks * d->ks * d->coutp;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (d->dtype == MI355_DT_F32) hipLaunchKernelGGL(wpack_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(wpack_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  return mi355_check_launch("weight_pack");
+}
+
+int32_t mi355_channel_stats_blocks(int64_t rows_per_group) {
+  long long b = (rows_per_group + kRowsPerStatBlock - 1) / kRowsPerStatBlock;
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;
+  return (int32_t)b;
+}
+
+int mi355_channel_stats(const void* x, int32_t ld, int32_t c, int64_t rows_per_group, int32_t groups, float* part,
+                        int32_t blocks_per_group, int32_t dtype, void* stream) {
+  MI355_REQUIRE(x && part && rows_per_group > 0 && groups > 0 && blocks_per_group > 0, "channel_stats: bad argument");
+  int rc = check_rows(c, ld, dtype, "channel_stats");
+  if (rc) return rc;
+  dim3 grid(blocks_per_group, groups);
+  if (dtype == MI355_DT_F32)
+    hipLaunchKernelGGL(channel_stats_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ld, c, (long long)rows_per_group, part, blocks_per_group);
+  else
+    hipLaunchKernelGGL(channel_stats_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, c, (long long)rows_per_group, part, blocks_per_group);
+  return mi355_check_launch("channel_stats");
+}
+
+int mi355_norm_finalize(const float* part, int32_t parts_per_group, int32_t groups, int32_t c, int64_t count_per_group,
+                        const float* shift, float eps, float* mean, float* rstd, float* running_mean,
+                        float* running_var, float momentum, void* stream) {
+  MI355_REQUIRE(part && mean && rstd && parts_per_group > 0 && groups > 0 && c > 0 && count_per_group > 0, "norm_finalize: bad argument");
+  MI355_REQUIRE(!running_mean || (running_var && groups == 1), "norm_finalize: running stats need groups == 1");
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3((c + 255) / 256, groups), dim3(256), 0, (hipStream_t)stream, part,
+                     parts_per_group, c, (long long)count_per_group, shift, eps, mean, rstd, running_mean, running_var, momentum);
+  return mi355_check_launch("norm_finalize");
+}
+
+int mi355_colsum_finalize(const float* part, int32_t parts, int32_t c, float* out, void* stream) {
+  MI355_REQUIRE(part && out && parts > 0 && c > 0, "colsum_finalize: bad argument");
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, parts, c, out);
+  return mi355_check_launch("colsum_finalize");
+}
+
+static int fill_normact(const mi355_normact_desc* d, NormActArgs* q, const char* who) {
+  MI355_REQUIRE(d && d->z, "%s: null pointer", who);
+  int rc = check_rows(d->c, d->ldz, d->dtype, who);
+  if (rc) return rc;
+  MI355_REQUIRE(d->rows_per_group > 0 && d->groups > 0, "%s: empty", who);
+  MI355_REQUIRE(!d->mean || d->rstd, "%s: mean without rstd", who);
+  MI355_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "%s: dropout p out of range", who);
+  q->z = (const char*)d->z; q->ldz = d->ldz; q->a = (char*)d->a; q->lda = d->lda;
+  q->c = d->c; q->rows_per_group = d->rows_per_group; q->groups = d->groups;
+  q->mean = d->mean; q->rstd = d->rstd; q->gamma = d->gamma; q->beta = d->beta;
+  q->slope = d->slope;
+  q->thr16 = d->drop_p > 0.f ? (unsigned)(d->drop_p * 65536.f + 0.5f) : 0u;
+  q->drop_scale = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
+  q->seed = d->seed;
+  q->da = (const char*)d->da; q->ldda = d->ldda; q->dz = (char*)d->dz; q->lddz = d->lddz;
+  q->part = d->part; q->blocks_per_group = d->blocks_per_group; q->sums = d->sums; q->batch_stats = d->batch_stats;
+  return MI355_OK;
+}
+
+static unsigned stream_blocks(long long rows, int c, int dtype) {
+  const int epv = dtype == MI355_DT_F32 ? 4 : 8;
+  const int rpp = 256 / (c / epv);
+  long long b = (rows + (long long)rpp * 8 - 1) / ((long long)rpp * 8);
+  if (b < 1) b = 1;
+  if (b > 4096) b = 4096;
+  return (unsigned)b;
+}
+
+int mi355_normact_fwd(const mi355_normact_desc* d, void* stream) {
+  NormActArgs q;
+  int rc = fill_normact(d, &q, "normact_fwd");
+  if (rc) return rc;
+  MI355_REQUIRE(d->a && d->lda >= d->c, "normact_fwd: bad output");
+  dim3 grid(stream_blocks(d->rows_per_group, d->c, d->dtype), d->groups);
+  if (d->dtype == MI355_DT_F32) hipLaunchKernelGGL(normact_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, q);
+  else hipLaunchKernelGGL(normact_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, q);
+  return mi355_check_launch("normact_fwd");
+}
+
+int mi355_normact_bwd_reduce(const mi355_normact_desc* d, void* stream) {
+  NormActArgs q;
+  int rc = fill_normact(d, &q, "normact_bwd_reduce");
+  if (rc) return rc;
+  MI355_REQUIRE(d->da && d->part && d->blocks_per_group > 0 && d->ldda >= d->c, "normact_bwd_reduce: bad argument");
+  dim3 grid(d->blocks_per_group, d->groups);
+  if (d->dtype == MI355_DT_F32) hipLaunchKernelGGL(normact_bwd_reduce_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, q);
+  else hipLaunchKernelGGL(normact_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, q);
+  return mi355_check_launch("normact_bwd_reduce");
+}
+
+int mi355_normact_bwd_finalize(const float* part, int32_t blocks_per_group, int32_t groups, int32_t c, float* sums,
+                               float* dgamma, float* dbeta, void* stream) {
+  MI355_REQUIRE(part && sums && blocks_per_group > 0 && groups > 0 && c > 0, "normact_bwd_finalize: bad argument");
+  hipLaunchKernelGGL(normact_bwd_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, part,
+                     blocks_per_group, groups, c, sums, dgamma, dbeta);
+  return mi355_check_launch("normact_bwd_finalize");
+}
+
+int mi355_normact_bwd_apply(const mi355_normact_desc* d, void* stream) {
+  NormActArgs q;
+  int rc = fill_normact(d, &q, "normact_bwd_apply");
+  if (rc) return rc;
+  MI355_REQUIRE(d->da && d->dz && d->ldda >= d->c && d->lddz >= d->c, "normact_bwd_apply: bad argument");
+  MI355_REQUIRE(!(d->mean && d->batch_stats) || d->sums, "normact_bwd_apply: sums required");
+  dim3 grid(stream_blocks(d->rows_per_group, d->c, d->dtype), d->groups);
+  if (d->dtype == MI355_DT_F32) hipLaunchKernelGGL(normact_bwd_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, q);
+  else hipLaunchKernelGGL(normact_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, q);
+  return mi355_check_launch("normact_bwd_apply");
+}
+
+int mi355_maxpool2_fwd(const void* x, int32_t ldx, void* y, int32_t ldy, int32_t n, int32_t c, int32_t d, int32_t h,
+                       int32_t w, int32_t dtype, void* stream) {
+  MI355_REQUIRE(x && y && n > 0, "maxpool_fwd: bad argument");
+  MI355_REQUIRE(d % 2 == 0 && h % 2 == 0 && w % 2 == 0 && d > 0 && h > 0 && w > 0, "maxpool: extents must be even (%d,%d,%d)", d, h, w);
+  int rc = check_rows(c, ldx, dtype, "maxpool_fwd");
+  if (rc) return rc;
+  rc = check_rows(c, ldy, dtype, "maxpool_fwd");
+  if (rc) return rc;
+  const int epv = dtype == MI355_DT_F32 ? 4 : 8;
+  const long long total = (long long)n * (d / 2) * (h / 2) * (w / 2) * (c / epv);
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (dtype == MI355_DT_F32)
+    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (float*)y, ldy, c, d, h, w, total);
+  else
+    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, c, d, h, w, total);
+  return mi355_check_launch("maxpool_fwd");
+}
+
+int mi355_maxpool2_bwd(const void* x, int32_t ldx, const void* y, int32_t ldy, const void* dy, int32_t lddy, void* dx,
+                       int32_t lddx, int32_t n, int32_t c, int32_t d, int32_t h, int32_t w, int32_t dtype, void* stream) {
+  MI355_REQUIRE(x && y && dy && dx && n > 0, "maxpool_bwd: bad argument");
+  MI355_REQUIRE(d % 2 == 0 && h % 2 == 0 && w % 2 == 0 && d > 0 && h > 0 && w > 0, "maxpool: extents must be even");
+  int rc = check_rows(c, ldx, dtype, "maxpool_bwd");
+  if (rc) return rc;
+  if ((rc = check_rows(c, ldy, dtype, "maxpool_bwd"))) return rc;
+  if ((rc = check_rows(c, lddy, dtype, "maxpool_bwd"))) return rc;
+  if ((rc = check_rows(c, lddx, dtype, "maxpool_bwd"))) return rc;
+  const int epv = dtype == MI355_DT_F32 ? 4 : 8;
+  const long long total = (long long)n * (d / 2) * (h / 2) * (w / 2) * (c / epv);
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (dtype == MI355_DT_F32)
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (const float*)y, ldy, (const float*)dy, lddy, (float*)dx, lddx, c, d, h, w, total);
+  else
+    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)y, ldy, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, c, d, h, w, total);
+  return mi355_check_launch("maxpool_bwd");
+}
+
+int32_t mi355_l1_blocks(int64_t count) { return (int32_t)((count + kL1PerBlock - 1) / kL1PerBlock); }
+
+int mi355_l1_fwd(const float* a, const float* b, int64_t count, float* partials, float* out, void* stream) {
+  MI355_REQUIRE(a && b && partials && out && count > 0, "l1_fwd: bad argument");
+  const int nb = mi355_l1_blocks(count);
+  hipLaunchKernelGGL(l1_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, b, (long long)count, partials);
+  hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nb, (long long)count, out);
+  return mi355_check_launch("l1_fwd");
+}
+
+int mi355_l1_bwd(const float* a, const float* b, int64_t count, const float* gscale, float* da, void* stream) {
+  MI355_REQUIRE(a && b && gscale && da && count > 0, "l1_bwd: bad argument");
+  long long nb = (count + 256 * 8 - 1) / (256 * 8);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(l1_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, a, b, (long long)count, gscale, da);
+  return mi355_check_launch("l1_bwd");
+}
+
+int mi355_adamw_multi(const void* const* ptrs, const int64_t* sizes, int32_t ntensors, int64_t max_size, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream) {
+  MI355_REQUIRE(ptrs && sizes && ntensors > 0 && max_size > 0 && step >= 1, "adamw: bad argument");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  long long nb = (max_size + 256 * 4 - 1) / (256 * 4);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)nb, ntensors), dim3(256), 0, (hipStream_t)stream, ptrs,
+                     (const long long*)sizes, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)));
+  return mi355_check_launch("adamw");
+}
+
+int mi355_mfma_selftest(float* out_f32_1024, float* out_bf16_1024, void* stream) {
+  MI355_REQUIRE(out_f32_1024 && out_bf16_1024, "selftest: null pointer");
+  hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out_f32_1024, out_bf16_1024);
+  return mi355_check_launch("selftest");
+}
+
+}  // extern "C"

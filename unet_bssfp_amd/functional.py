@@ -1,0 +1,347 @@
+"""Autograd operators of the path: each forward/backward is a sequence of C-ABI launches
+(``ops``); torch.autograd only orders them and accumulates parameter gradients, so
+``requires_grad_`` toggling (Lightning ``toggle_optimizer``, src/model.py:264,274), DDP hooks and
+back-propagation through the discriminator into the generator (src/model.py:172,268) work as
+with the reference's stock modules."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import ops
+from .ops import round_up
+
+CLASSES8 = [(a, b, c) for a in (0, 1) for b in (0, 1) for c in (0, 1)]
+
+_WEIGHT_EPOCH = 0
+
+
+def bump_weight_epoch():
+    """Called by optimisers that update parameters through raw pointers (no autograd version bump)."""
+    global _WEIGHT_EPOCH
+    _WEIGHT_EPOCH += 1
+
+
+class LayerCache:
+    """Packed-weight cache of one convolution (re-packed when the parameter changes)."""
+
+    def __init__(self):
+        self._store = {}
+
+    def get(self, key, tensor: torch.Tensor, builder):
+        tag = (tensor._version, tensor.data_ptr(), tensor.device, _WEIGHT_EPOCH)
+        hit = self._store.get(key)
+        if hit is not None and hit[0] == tag:
+            return hit[1]
+        val = builder()
+        self._store[key] = (tag, val)
+        return val
+
+    def clear(self):
+        self._store.clear()
+
+
+def _padded(vec: Optional[torch.Tensor], n: int, fill: float = 0.0) -> Optional[torch.Tensor]:
+    if vec is None:
+        return None
+    v = vec.detach()
+    if v.numel() == n:
+        return v.contiguous()
+    out = torch.full((n,), fill, dtype=torch.float32, device=v.device)
+    out[: v.numel()] = v
+    return out
+
+
+# ====================================================================================== layout
+class PackFn(Function):
+    """NCDHW f32 tensors -> one NDHWC activation (virtual torch.cat along channels + layout)."""
+
+    @staticmethod
+    def forward(ctx, cp, dtype, *srcs):
+        n, _, d, h, w = srcs[0].shape
+        epv = 4 if dtype == torch.float32 else 8
+        ctx.split = None
+        if len(srcs) > 1 and any(s.shape[1] % epv for s in srcs[:-1]):
+            # channel boundaries that are not 16-byte aligned: concatenate first (boundary plumbing)
+            ctx.split = [s.shape[1] for s in srcs]
+            srcs = (torch.cat([s.detach().to(torch.float32) for s in srcs], dim=1),)
+        out = ops.new_act(n, d, h, w, cp, dtype, srcs[0].device)
+        offs, off = [], 0
+        for i, s in enumerate(srcs):
+            c = s.shape[1]
+            last = i == len(srcs) - 1
+            s32 = s.detach().to(torch.float32).contiguous()
+            ops.pack_ncdhw(s32, out, off, cp if last else off + c)
+            offs.append((off, c))
+            off += c
+        ctx.offs = offs
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        g = ops.as_act(g)
+        grads = []
+        if ctx.split is not None:
+            full = ops.unpack_ncdhw(g, sum(ctx.split), 0)
+            pieces = torch.split(full, ctx.split, dim=1)
+            grads = [pc.contiguous() if ctx.needs_input_grad[2 + i] else None for i, pc in enumerate(pieces)]
+            return (None, None, *grads)
+        for i, (off, c) in enumerate(ctx.offs):
+            grads.append(ops.unpack_ncdhw(g, c, off) if ctx.needs_input_grad[2 + i] else None)
+        return (None, None, *grads)
+
+
+class UnpackFn(Function):
+    """NDHWC activation -> contiguous NCDHW f32 (the tensor handed back to the caller)."""
+
+    @staticmethod
+    def forward(ctx, act, c):
+        ctx.meta = (act.shape[4], act.dtype)
+        return ops.unpack_ncdhw(act, c, 0)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        cp, dtype = ctx.meta
+        n, c, d, h, w = g.shape
+        out = ops.new_act(n, d, h, w, cp, dtype, g.device)
+        ops.pack_ncdhw(g.to(torch.float32).contiguous(), out, 0, cp)
+        return out, None
+
+
+# ====================================================================================== conv
+class ConvSpec:
+    """Static description of one convolution layer (+ its packed-weight cache)."""
+
+    def __init__(self, kind, cin, cout, ks, stride, pad):
+        assert kind in ("conv", "deconv2")
+        self.kind, self.cin, self.cout, self.ks, self.stride, self.pad = kind, cin, cout, ks, stride, pad
+        self.cache = LayerCache()
+
+    # ---- packed weights --------------------------------------------------------------
+    def w_fwd(self, w, dtype, cinp):
+        k = self.ks
+        return self.cache.get(("fwd", dtype, cinp), w, lambda: ops.weight_pack(
+            w.detach(), self.cout, self.cin, k, self.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (1, 1, 1),
+            dtype, cinp))
+
+    def w_dgrad_s1(self, w, dtype, cinp, coutp_min):
+        k = self.ks
+        return self.cache.get(("dgrad", dtype, cinp), w, lambda: ops.weight_pack(
+            w.detach(), self.cin, self.cout, k, k ** 3, self.cin * k ** 3, (k * k, k, 1), (k - 1,) * 3, (-1,) * 3,
+            dtype, cinp))
+
+    def w_dgrad_s2(self, w, dtype, cinp, cls):
+        # k4 s2 p1 transposed: parity class p per dim uses taps {3,1} (p=0) or {2,0} (p=1)
+        k = self.ks
+        tb = tuple(3 if p == 0 else 2 for p in cls)
+        return self.cache.get(("dgrad2", dtype, cinp, cls), w, lambda: ops.weight_pack(
+            w.detach(), self.cin, self.cout, 2, k ** 3, self.cin * k ** 3, (k * k, k, 1), tb, (-2,) * 3, dtype, cinp))
+
+    def w_deconv_fwd(self, w, dtype, cinp, cls):
+        # ConvTranspose3d weight (Cin, Cout, 2,2,2): class = output parity = tap
+        return self.cache.get(("dfwd", dtype, cinp, cls), w, lambda: ops.weight_pack(
+            w.detach(), self.cout, self.cin, 1, 8, self.cout * 8, (4, 2, 1), cls, (0, 0, 0), dtype, cinp))
+
+    def w_deconv_dgrad(self, w, dtype, cinp):
+        return self.cache.get(("ddgrad", dtype, cinp), w, lambda: ops.weight_pack(
+            w.detach(), self.cin, self.cout, 2, self.cout * 8, 8, (4, 2, 1), (0, 0, 0), (1, 1, 1), dtype, cinp))
+
+    def out_extent(self, e):
+        if self.kind == "deconv2":
+            return 2 * e
+        return (e + 2 * self.pad - self.ks) // self.stride + 1
+
+
+class ConvFn(Function):
+    """z = conv(x0 | x1) + bias  (optionally with fused per-tile channel statistics)."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, spec: ConvSpec, want_stats: bool):
+        x0 = ops.as_act(x0)
+        x1 = ops.as_act(x1) if x1 is not None else None
+        n, di, hi, wi, c0 = x0.shape
+        c1 = x1.shape[4] if x1 is not None else 0
+        dtype, dev = x0.dtype, x0.device
+        cp = round_up(spec.cout, 16)
+        do_, ho, wo = (spec.out_extent(e) for e in (di, hi, wi))
+        out = ops.new_act(n, do_, ho, wo, cp, dtype, dev)
+        part = None
+        if spec.kind == "conv":
+            wp, coutp, _ = spec.w_fwd(weight, dtype, c0 + c1)
+            bp = _padded(bias, coutp)
+            pad3 = (spec.pad,) * 3
+            if want_stats:
+                tiles, _ = ops.conv_num_tiles(x0, x1, wp, coutp, spec.ks, spec.stride, pad3, out, (do_, ho, wo))
+                part = torch.empty((tiles, 2, coutp), dtype=torch.float32, device=dev)
+            ops.conv_fwd(x0, x1, wp, coutp, bp, spec.ks, spec.stride, pad3, out, (do_, ho, wo), stats=part)
+        else:
+            assert x1 is None and not want_stats
+            for cls in CLASSES8:
+                wp, coutp, _ = spec.w_deconv_fwd(weight, dtype, c0, cls)
+                bp = _padded(bias, coutp)
+                ops.conv_fwd(x0, None, wp, coutp, bp, 1, 1, (0, 0, 0), out, (di, hi, wi), os=2, ooff=cls)
+        ctx.save_for_backward(x0, x1, weight)
+        ctx.spec = spec
+        ctx.has_bias = bias is not None
+        if part is None:
+            part = torch.empty((0,), dtype=torch.float32, device=dev)
+        ctx.mark_non_differentiable(part)
+        return out, part
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz, _dpart):
+        x0, x1, weight = ctx.saved_tensors
+        spec: ConvSpec = ctx.spec
+        dz = ops.as_act(dz)
+        n, di, hi, wi, c0 = x0.shape
+        c1 = x1.shape[4] if x1 is not None else 0
+        dtype, dev = x0.dtype, x0.device
+        do_, ho, wo = dz.shape[1:4]
+        cg = dz.shape[4]
+        k = spec.ks
+        dx0 = dx1 = dw = db = None
+        need_dx = ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1])
+        if need_dx:
+            dxc = ops.new_act(n, di, hi, wi, c0 + c1, dtype, dev)
+            if spec.kind == "conv" and spec.stride == 1:
+                wp, coutp, _ = spec.w_dgrad_s1(weight, dtype, cg, c0 + c1)
+                ops.conv_fwd(dz, None, wp, coutp, None, k, 1, (k - 1 - spec.pad,) * 3, dxc, (di, hi, wi))
+            elif spec.kind == "conv":
+                if not (k == 4 and spec.stride == 2 and spec.pad == 1 and di % 2 == 0 and hi % 2 == 0 and wi % 2 == 0):
+                    raise NotImplementedError("strided data gradient is implemented for k4 s2 p1 on even extents")
+                for cls in CLASSES8:
+                    wp, coutp, _ = spec.w_dgrad_s2(weight, dtype, cg, cls)
+                    pad3 = tuple(1 if p == 0 else 0 for p in cls)
+                    ops.conv_fwd(dz, None, wp, coutp, None, 2, 1, pad3, dxc, (di // 2, hi // 2, wi // 2), os=2, ooff=cls)
+            else:
+                wp, coutp, _ = spec.w_deconv_dgrad(weight, dtype, cg)
+                ops.conv_fwd(dz, None, wp, coutp, None, 2, 2, (0, 0, 0), dxc, (di, hi, wi))
+            dx0 = dxc[..., :c0] if c1 else dxc
+            dx1 = dxc[..., c0:] if c1 else None
+        if ctx.needs_input_grad[2]:
+            dw = torch.empty_like(weight, dtype=torch.float32)
+            if spec.kind == "conv":
+                ops.conv_wgrad(x0, x1, dz, (do_, ho, wo), 1, (0, 0, 0), k, spec.stride, (spec.pad,) * 3, dw,
+                               spec.cout, spec.cin, spec.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (1, 1, 1))
+            else:
+                for cls in CLASSES8:
+                    ops.conv_wgrad(x0, None, dz, (di, hi, wi), 2, cls, 1, 1, (0, 0, 0), dw,
+                                   spec.cout, spec.cin, 8, spec.cout * 8, (4, 2, 1), cls, (0, 0, 0))
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            db = ops.colsum(dz)[: spec.cout].contiguous()
+        return dx0, dx1, dw, db, None, None
+
+
+# ====================================================================================== norm + act
+class NormCfg:
+    def __init__(self, kind, channels, eps=1e-5, momentum=0.1, slope=1.0, p=0.0):
+        assert kind in ("instance", "batch", "none")
+        self.kind, self.channels, self.eps, self.momentum, self.slope, self.p = kind, channels, eps, momentum, slope, p
+
+
+def _draw_seed() -> int:
+    # host-side draw from torch's CPU generator: reproducible under torch.manual_seed, no device sync
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+class NormActFn(Function):
+    """a = LeakyReLU(Dropout(Norm(z)))  -- MONAI ADN "NDA" / BatchNorm3d + LeakyReLU."""
+
+    @staticmethod
+    def forward(ctx, z, part, gamma, beta, conv_bias, cfg: NormCfg, training, running_mean, running_var):
+        z = ops.as_act(z)
+        n, d, h, w, c = z.shape
+        rows = n * d * h * w
+        groups = n if cfg.kind == "instance" else 1
+        mean = rstd = None
+        batch_stats = False
+        if cfg.kind != "none":
+            use_batch = cfg.kind == "instance" or training or running_mean is None
+            if use_batch:
+                if rows // groups <= 1:
+                    raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(z.shape)}")
+                if part is not None and part.numel() > 0:
+                    assert part.shape[2] == c, "fused statistics need coutp == padded channels"
+                    ppg = part.shape[0] // groups
+                    shift = _padded(conv_bias, c)
+                else:
+                    part, ppg = ops.channel_stats(z, groups)
+                    shift = None
+                upd = cfg.kind == "batch" and training and running_mean is not None
+                rm = rv = None
+                if upd:
+                    # running buffers may be shorter than the padded channel count
+                    rm = running_mean if running_mean.numel() == c else _padded(running_mean, c)
+                    rv = running_var if running_var.numel() == c else _padded(running_var, c, 1.0)
+                mean, rstd = ops.norm_finalize(part, ppg, groups, c, rows // groups, shift, cfg.eps, rm, rv, cfg.momentum)
+                if upd and rm is not running_mean:
+                    running_mean.copy_(rm[: running_mean.numel()])
+                    running_var.copy_(rv[: running_var.numel()])
+                batch_stats = True
+            else:
+                mean = _padded(running_mean, c).reshape(1, c)
+                rstd = torch.rsqrt(_padded(running_var, c, 1.0) + cfg.eps).reshape(1, c)
+        gp, bp = _padded(gamma, c), _padded(beta, c)
+        p = cfg.p if training else 0.0
+        seed = _draw_seed() if p > 0.0 else 0
+        a = ops.normact_fwd(z, groups, mean, rstd, gp, bp, cfg.slope, p, seed)
+        ctx.save_for_backward(z, mean, rstd, gp, bp)
+        ctx.meta = (groups, cfg.slope, p, seed, batch_stats, gamma.numel() if gamma is not None else 0)
+        return a
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, da):
+        z, mean, rstd, gp, bp = ctx.saved_tensors
+        groups, slope, p, seed, batch_stats, nch = ctx.meta
+        da = ops.as_act(da)
+        want_affine = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        dz, dgamma, dbeta = ops.normact_bwd(z, da, groups, mean, rstd, gp, bp, slope, p, seed, batch_stats,
+                                            want_affine and mean is not None)
+        dg = dgamma[:nch].contiguous() if (dgamma is not None and ctx.needs_input_grad[2]) else None
+        dbt = dbeta[:nch].contiguous() if (dbeta is not None and ctx.needs_input_grad[3]) else None
+        return dz, None, dg, dbt, None, None, None, None, None
+
+
+# ====================================================================================== pool / loss
+class MaxPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = ops.as_act(x)
+        y = ops.maxpool2_fwd(x)
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        return ops.maxpool2_bwd(x, y, ops.as_act(dy))
+
+
+class L1LossFn(Function):
+    """torch.nn.L1Loss()(a, b) (mean reduction) on contiguous f32 tensors (src/model.py:126,136)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a = a.contiguous()
+        b = b.contiguous()
+        ctx.save_for_backward(a, b)
+        return ops.l1_fwd(a, b)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        da = ops.l1_bwd(a, b, g)
+        return (da if ctx.needs_input_grad[0] else None, (-da) if ctx.needs_input_grad[1] else None)
+
+
+def l1_loss(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    return L1LossFn.apply(a, b)

@@ -1,0 +1,162 @@
+"""GAN training step of the reference LightningModule, without Lightning.
+
+``bSSFPToDWITensorModel`` mirrors the attribute and method names of the reference class
+(src/model.py:141-213, 259-281, 359-361) so that the parity tests read like the reference:
+``gen``, ``discr``, ``unpack_batch``, ``_gen_step``, ``_discr_step``, ``compute_recon_loss``,
+``training_step``, ``configure_optimizers``.  What Lightning did implicitly is explicit here:
+
+* ``toggle_optimizer`` / ``untoggle_optimizer``  -> ``requires_grad_`` on the other network
+* ``manual_backward``                             -> ``loss.backward()``
+* ``self.log(..., sync_dist=True)`` x6            -> ONE stacked tensor, reduced once per step
+  by the caller (no host sync inside the step)
+* DDP gradient all-reduce                         -> ``GradSync`` hooks (``ddp.py``), one per network
+
+The Perceptual term (src/model.py:127-129) needs remotely fetched MedicalNet weights; it is a
+pluggable slot (``extra_recon_terms``) and absent by default, as stated wherever numbers are
+reported.  The module is agnostic of where ``gen``/``discr`` come from, so the same step logic
+drives the CPU oracle modules in the tests.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Callable, Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+DATA = "data"  # tio.DATA
+
+LOG_KEYS = ("gen_loss_adversarial", "gen_loss_recon_L1", "gen_loss_recon", "gen_loss", "discr_loss")
+
+
+class bSSFPToDWITensorModel(nn.Module):
+    def __init__(self, input_modality, lr=1e-3, batch_size=8, perceptual_factor=1e3, recon_factor=1e2,
+                 gen: Optional[nn.Module] = None, discr: Optional[nn.Module] = None,
+                 l1_fn: Optional[Callable] = None, optimizer_class=None,
+                 extra_recon_terms: Optional[Dict[str, Callable]] = None):
+        super().__init__()
+        self.input_modality = input_modality
+        if gen is None or discr is None:
+            from .nn import Discriminator, Generator
+            gen = Generator(input_modality) if gen is None else gen
+            discr = Discriminator(input_modality) if discr is None else discr
+        self.gen, self.discr = gen, discr
+        self.recon_factor, self.lr, self.batch_size = recon_factor, lr, batch_size
+        self.perceptual_factor = perceptual_factor
+        self.l1_fn = l1_fn
+        self.extra_recon_terms = extra_recon_terms or {}
+        self.optimizer_class = optimizer_class
+        self.grad_sync_gen = None      # set by ddp.attach(); called after each phase's backward
+        self.grad_sync_discr = None
+        self._optimizers = None
+        self.last_logs: Dict[str, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, x):
+        return self.gen(x)
+
+    def configure_optimizers(self):
+        cls = self.optimizer_class
+        if cls is None:
+            from .optim import FusedAdamW
+            cls = FusedAdamW if next(self.gen.parameters()).is_cuda else torch.optim.AdamW
+        return cls(self.gen.parameters(), lr=self.lr), cls(self.discr.parameters(), lr=self.lr)
+
+    def optimizers(self):
+        if self._optimizers is None:
+            self._optimizers = self.configure_optimizers()
+        return self._optimizers
+
+    def unpack_batch(self, batch, test=False):
+        x = batch[self.input_modality][DATA]
+        y = batch["dwi-tensor" if test else "dwi-tensor_orig"][DATA]
+        return x, y
+
+    def _l1(self, a, b):
+        if self.l1_fn is not None:
+            return self.l1_fn(a, b)
+        if a.is_cuda:
+            from .functional import l1_loss
+            return l1_loss(a, b)
+        return F.l1_loss(a, b)
+
+    def compute_recon_loss(self, y_hat, y, logs, prefix):
+        terms = OrderedDict(L1=self._l1(y_hat, y))
+        for name, fn in self.extra_recon_terms.items():
+            terms[name] = fn(y_hat, y)
+        total = None
+        for name, t in terms.items():
+            logs[f"{prefix}_loss_recon_{name}"] = t.detach()
+            total = t if total is None else total + t
+        total = total / len(terms) * self.recon_factor
+        logs[f"{prefix}_loss_recon"] = total.detach()
+        return total
+
+    def _gen_step(self, x, y, logs, prefix="gen"):
+        y_hat = self.gen(x)
+        logits = self.discr(x, y_hat)
+        adv = F.binary_cross_entropy_with_logits(logits, torch.ones_like(logits))
+        recon = self.compute_recon_loss(y_hat, y, logs, prefix)
+        logs[f"{prefix}_loss_adversarial"] = adv.detach()
+        return adv + recon, y_hat
+
+    def _discr_step(self, x, y):
+        y_hat = self.gen(x).detach()
+        logits_hat = self.discr(x, y_hat)
+        logits = self.discr(x, y)
+        loss_hat = F.binary_cross_entropy_with_logits(logits_hat, torch.zeros_like(logits_hat))
+        loss = F.binary_cross_entropy_with_logits(logits, torch.ones_like(logits))
+        return (loss + loss_hat) / 2
+
+    @staticmethod
+    def _toggle(module: nn.Module, flag: bool):
+        for p in module.parameters():
+            p.requires_grad_(flag)
+
+    def training_step(self, batch, batch_idx=0):
+        x, y = self.unpack_batch(batch)
+        gen_opt, discr_opt = self.optimizers()
+        logs: Dict[str, torch.Tensor] = {}
+
+        # ---- generator phase
+        self._toggle(self.discr, False)
+        loss, _ = self._gen_step(x, y, logs)
+        logs["gen_loss"] = loss.detach()
+        loss.backward()
+        if self.grad_sync_gen is not None:
+            self.grad_sync_gen.finish()
+        gen_opt.step()
+        gen_opt.zero_grad()
+        self._toggle(self.discr, True)
+
+        # ---- discriminator phase
+        self._toggle(self.gen, False)
+        loss = self._discr_step(x, y)
+        logs["discr_loss"] = loss.detach()
+        loss.backward()
+        if self.grad_sync_discr is not None:
+            self.grad_sync_discr.finish()
+        discr_opt.step()
+        discr_opt.zero_grad()
+        self._toggle(self.gen, True)
+        self.last_logs = logs
+        return None
+
+    def stacked_logs(self) -> torch.Tensor:
+        """The step's scalars as ONE tensor (order: LOG_KEYS) -- a single all-reduce replaces the
+        reference's six ``sync_dist`` logs."""
+        return torch.stack([self.last_logs[k].reshape(()).float() for k in LOG_KEYS])
+
+
+def synthetic_batch(n: int, s, seed: int, modality: str = "bssfp", device="cpu"):
+    """The dict layout ``unpack_batch`` expects (src/model.py:195-199), U[0,1) volumes
+    (all modalities are min-max normalised: doc/thesis/03-methods.tex:670)."""
+    cin = 24 if modality in ("bssfp", "pc-bssfp") else 6
+    if isinstance(s, int):
+        s = (s, s, s)
+    g = torch.Generator("cpu").manual_seed(seed)
+    x = torch.rand(n, cin, *s, generator=g)
+    y = torch.rand(n, 6, *s, generator=g)
+    x, y = x.to(device), y.to(device)
+    return {modality: {DATA: x}, "dwi-tensor_orig": {DATA: y}, "dwi-tensor": {DATA: y}}

@@ -1,0 +1,335 @@
+"""Drop-in ``torch.nn.Module``s for the three construction sites of the reference hot path
+(SURVEY.md 8(b)): same constructor signatures, same ``state_dict`` keys and shapes, f32
+``nn.Parameter`` leaves, but every FLOP runs in the hand-written gfx950 kernels behind the C ABI.
+
+* ``DownSampleConv``  <- src/model.py:42-65
+* ``Discriminator``   <- src/model.py:68-92
+* ``BasicUNet``       <- monai.networks.nets.BasicUNet as constructed at src/model.py:22-28
+* ``Generator``       <- src/model.py:15-39
+
+Public ``forward`` takes / returns logical NCDHW tensors like the reference modules.  Between our
+own modules activations travel as NDHWC buffers (``forward_act``); a tensor returned by ``forward``
+is an NCDHW *view* of such a buffer and carries it along (``_mi355_act``), so a reference-side
+``Generator.forward`` that chains head -> unet pays no layout conversion.
+
+GPU only: there is no CPU path here (the CPU restatement lives in ``oracle/`` and is test-only).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+from . import ops
+from .ops import round_up
+
+_DEFAULT_DTYPE = torch.float32
+
+
+def set_default_compute_dtype(dtype: torch.dtype):
+    global _DEFAULT_DTYPE
+    assert dtype in (torch.float32, torch.bfloat16)
+    _DEFAULT_DTYPE = dtype
+
+
+def set_compute_dtype(module: nn.Module, dtype: torch.dtype) -> nn.Module:
+    """Arithmetic/storage type of the activations (f32: parity mode, bf16: throughput mode)."""
+    assert dtype in (torch.float32, torch.bfloat16)
+    for m in module.modules():
+        if isinstance(m, _Mi355Module):
+            m.compute_dtype = dtype
+    return module
+
+
+class _Mi355Module(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.compute_dtype = _DEFAULT_DTYPE
+
+    # ---- boundary helpers ----------------------------------------------------------------
+    def _to_act(self, x: torch.Tensor, cp: Optional[int] = None) -> torch.Tensor:
+        ops.require_cuda(x)
+        act = getattr(x, "_mi355_act", None)
+        if act is not None and act.dtype == self.compute_dtype and (cp is None or act.shape[4] == cp):
+            return act
+        if x.dim() != 5:
+            raise ValueError(f"expected a 5-D (N,C,D,H,W) tensor, got {tuple(x.shape)}")
+        cp = round_up(x.shape[1], 16) if cp is None else cp
+        return Fn.PackFn.apply(cp, self.compute_dtype, x)
+
+    @staticmethod
+    def _from_act(act: torch.Tensor, c: int) -> torch.Tensor:
+        v = act.permute(0, 4, 1, 2, 3)
+        if c != act.shape[4]:
+            v = v[:, :c]
+        v._mi355_act = act
+        return v
+
+
+# ------------------------------------------------------------------------------------------
+class Conv3d(_Mi355Module):
+    """torch.nn.Conv3d(in, out, kernel_size, stride, padding, bias) -- cubic kernels 1..4."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        k = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
+        s = stride if isinstance(stride, int) else stride[0]
+        p = padding if isinstance(padding, int) else padding[0]
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = (k,) * 3, (s,) * 3, (p,) * 3
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, k, k, k))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.spec = Fn.ConvSpec("conv", in_channels, out_channels, k, s, p)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # identical to torch.nn.modules.conv._ConvNd.reset_parameters (same RNG consumption)
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = nn.init._calculate_fan_in_and_fan_out(self.weight)
+            bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward_act(self, x0, x1=None, want_stats=False):
+        return Fn.ConvFn.apply(x0, x1, self.weight, self.bias, self.spec, want_stats)
+
+    def forward(self, x):
+        z, _ = self.forward_act(self._to_act(x))
+        return self._from_act(z, self.out_channels)
+
+
+class ConvTranspose3d(_Mi355Module):
+    """torch.nn.ConvTranspose3d(in, out, kernel_size=2, stride=2, bias) (MONAI UpSample 'deconv')."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=2, stride=2, bias=True):
+        super().__init__()
+        if kernel_size != 2 or stride != 2:
+            raise NotImplementedError("only the k2 s2 transposed convolution of BasicUNet is implemented")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = nn.Parameter(torch.empty(in_channels, out_channels, 2, 2, 2))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.spec = Fn.ConvSpec("deconv2", in_channels, out_channels, 2, 2, 0)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = nn.init._calculate_fan_in_and_fan_out(self.weight)
+            bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward_act(self, x):
+        return Fn.ConvFn.apply(x, None, self.weight, self.bias, self.spec, False)[0]
+
+    def forward(self, x):
+        return self._from_act(self.forward_act(self._to_act(x)), self.out_channels)
+
+
+class _NormParams(nn.Module):
+    """Parameter holder with torch's names: weight, bias (+ BatchNorm buffers)."""
+
+    def __init__(self, channels, batch: bool):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(channels))
+        self.bias = nn.Parameter(torch.zeros(channels))
+        if batch:
+            self.register_buffer("running_mean", torch.zeros(channels))
+            self.register_buffer("running_var", torch.ones(channels))
+            self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+# ------------------------------------------------------------------------------------------
+class DownSampleConv(_Mi355Module):
+    """src/model.py:42-65: Conv3d -> [BatchNorm3d] -> [LeakyReLU(0.2)], defaults k4 s2 p1."""
+
+    def __init__(self, in_channels, out_channels, kernel=4, strides=2, padding=1, activation=True, batchnorm=True):
+        super().__init__()
+        self.activation = activation
+        self.batchnorm = batchnorm
+        self.conv = Conv3d(in_channels, out_channels, kernel, strides, padding)
+        if batchnorm:
+            self.bn = _NormParams(out_channels, batch=True)
+        self.cfg = Fn.NormCfg("batch" if batchnorm else "none", out_channels, eps=1e-5, momentum=0.1,
+                              slope=0.2 if activation else 1.0)
+
+    def forward_act(self, x0, x1=None):
+        fuse = self.batchnorm and self.training
+        z, part = self.conv.forward_act(x0, x1, want_stats=fuse)
+        if not (self.batchnorm or self.activation):
+            return z
+        if self.batchnorm:
+            a = Fn.NormActFn.apply(z, part if fuse else None, self.bn.weight, self.bn.bias, self.conv.bias,
+                                   self.cfg, self.training, self.bn.running_mean, self.bn.running_var)
+            if self.training:
+                self.bn.num_batches_tracked += 1
+            return a
+        return Fn.NormActFn.apply(z, None, None, None, None, self.cfg, self.training, None, None)
+
+    def forward(self, x):
+        return self._from_act(self.forward_act(self._to_act(x)), self.conv.out_channels)
+
+
+class Discriminator(_Mi355Module):
+    """src/model.py:68-92 (PatchGAN): cat(x, y) -> d1[modality] -> d2..d5 -> 1x1x1 conv, raw logits."""
+
+    def __init__(self, modality):
+        super().__init__()
+        self.modality = modality
+        d1_bssfp = DownSampleConv(30, 32, batchnorm=False)
+        d1_dwi = DownSampleConv(12, 32, batchnorm=False)
+        self.d1 = self.blocks = nn.ModuleDict({"dwi-tensor": d1_dwi, "pc-bssfp": d1_bssfp,
+                                               "bssfp": d1_bssfp, "t1w": d1_dwi})
+        self.d2 = DownSampleConv(32, 64)
+        self.d3 = DownSampleConv(64, 128)
+        self.d4 = DownSampleConv(128, 256)
+        self.d5 = DownSampleConv(256, 512)
+        self.final = Conv3d(512, 1, kernel_size=1)
+
+    def forward(self, x, y):
+        ops.require_cuda(x, y)
+        cin = x.shape[1] + y.shape[1]
+        h = Fn.PackFn.apply(round_up(cin, 16), self.compute_dtype, x, y)    # torch.cat([x, y], 1) + layout
+        h = self.d1[self.modality].forward_act(h)
+        for blk in (self.d2, self.d3, self.d4, self.d5):
+            h = blk.forward_act(h)
+        z, _ = self.final.forward_act(h)
+        return Fn.UnpackFn.apply(z, 1)
+
+
+# ------------------------------------------------------------------------------------------
+# monai.networks.nets.BasicUNet (module/parameter names follow MONAI's state_dict)
+class _ADN(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.N = _NormParams(channels, batch=False)
+
+
+class Convolution(_Mi355Module):
+    """MONAI Convolution(k3, s1, p1, adn_ordering="NDA"): Conv3d -> InstanceNorm3d(affine) ->
+    Dropout(p) -> LeakyReLU(0.1), fused as conv(+statistics) -> finalize -> one apply pass."""
+
+    def __init__(self, cin, cout, dropout, slope=0.1, eps=1e-5):
+        super().__init__()
+        self.conv = Conv3d(cin, cout, 3, 1, 1, bias=True)
+        self.adn = _ADN(cout)
+        self.cfg = Fn.NormCfg("instance", cout, eps=eps, slope=slope, p=float(dropout or 0.0))
+
+    def forward_act(self, x0, x1=None):
+        z, part = self.conv.forward_act(x0, x1, want_stats=True)
+        return Fn.NormActFn.apply(z, part, self.adn.N.weight, self.adn.N.bias, self.conv.bias, self.cfg,
+                                  self.training, None, None)
+
+
+class TwoConv(_Mi355Module):
+    def __init__(self, cin, cout, dropout):
+        super().__init__()
+        self.conv_0 = Convolution(cin, cout, dropout)
+        self.conv_1 = Convolution(cout, cout, dropout)
+
+    def forward_act(self, x0, x1=None):
+        return self.conv_1.forward_act(self.conv_0.forward_act(x0, x1))
+
+
+class Down(_Mi355Module):
+    def __init__(self, cin, cout, dropout):
+        super().__init__()
+        self.convs = TwoConv(cin, cout, dropout)
+
+    def forward_act(self, x):
+        return self.convs.forward_act(Fn.MaxPoolFn.apply(x))
+
+
+class _UpSample(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.deconv = ConvTranspose3d(cin, cout, 2, 2, bias=True)
+
+
+class UpCat(_Mi355Module):
+    def __init__(self, cin, ccat, cout, dropout, halves=True):
+        super().__init__()
+        cup = cin // 2 if halves else cin
+        self.upsample = _UpSample(cin, cup)
+        self.convs = TwoConv(ccat + cup, cout, dropout)
+
+    def forward_act(self, x, x_e):
+        x_0 = self.upsample.deconv.forward_act(x)
+        if x_0.shape[1:4] != x_e.shape[1:4]:
+            raise NotImplementedError("odd skip extents (MONAI replicate-pad branch) are not implemented: "
+                                      "spatial sizes must be divisible by 16")
+        return self.convs.forward_act(x_e, x_0)        # virtual cat([x_e, x_0], 1): skip first
+
+
+class BasicUNet(_Mi355Module):
+    """BasicUNet(spatial_dims=3, in_channels, out_channels, features, act, norm, bias, dropout, upsample)."""
+
+    def __init__(self, spatial_dims: int = 3, in_channels: int = 1, out_channels: int = 2,
+                 features: Sequence[int] = (32, 32, 64, 128, 256, 32),
+                 act=("LeakyReLU", {"negative_slope": 0.1, "inplace": True}),
+                 norm=("instance", {"affine": True}), bias: bool = True, dropout=0.0, upsample: str = "deconv"):
+        super().__init__()
+        if spatial_dims != 3:
+            raise NotImplementedError("the MI355X path implements the reference's 3-D configuration")
+        if upsample != "deconv" or not bias:
+            raise NotImplementedError("only upsample='deconv', bias=True (the reference's configuration)")
+        act_name = act[0] if isinstance(act, (tuple, list)) else act
+        norm_name = norm[0] if isinstance(norm, (tuple, list)) else norm
+        if str(act_name).lower() != "leakyrelu" or str(norm_name).lower() != "instance":
+            raise NotImplementedError("only act=LeakyReLU / norm=instance (MONAI defaults used by the reference)")
+        f = tuple(features)
+        if len(f) != 6:
+            raise ValueError("features must have 6 entries")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.conv_0 = TwoConv(in_channels, f[0], dropout)
+        self.down_1 = Down(f[0], f[1], dropout)
+        self.down_2 = Down(f[1], f[2], dropout)
+        self.down_3 = Down(f[2], f[3], dropout)
+        self.down_4 = Down(f[3], f[4], dropout)
+        self.upcat_4 = UpCat(f[4], f[3], f[3], dropout)
+        self.upcat_3 = UpCat(f[3], f[2], f[2], dropout)
+        self.upcat_2 = UpCat(f[2], f[1], f[1], dropout)
+        self.upcat_1 = UpCat(f[1], f[0], f[5], dropout, halves=False)
+        self.final_conv = Conv3d(f[5], out_channels, kernel_size=1)
+
+    def forward_act(self, x):
+        for e in x.shape[1:4]:
+            if e % 16 != 0 or e // 16 < 2:
+                raise ValueError(f"spatial extents must be divisible by 16 and >= 32 (InstanceNorm needs > 1 "
+                                 f"element at the bottom level), got {tuple(x.shape[1:4])}")
+        x0 = self.conv_0.forward_act(x)
+        x1 = self.down_1.forward_act(x0)
+        x2 = self.down_2.forward_act(x1)
+        x3 = self.down_3.forward_act(x2)
+        x4 = self.down_4.forward_act(x3)
+        u4 = self.upcat_4.forward_act(x4, x3)
+        u3 = self.upcat_3.forward_act(u4, x2)
+        u2 = self.upcat_2.forward_act(u3, x1)
+        u1 = self.upcat_1.forward_act(u2, x0)
+        z, _ = self.final_conv.forward_act(u1)
+        return z
+
+    def forward(self, x):
+        z = self.forward_act(self._to_act(x, round_up(self.in_channels, 16)))
+        return Fn.UnpackFn.apply(z, self.out_channels)
+
+
+class Generator(_Mi355Module):
+    """src/model.py:15-39: modality head (1x1x1 DownSampleConv) -> BasicUNet(24 -> 6)."""
+
+    def __init__(self, input_modality, dropout=0.05, features=(32, 64, 128, 256, 512, 32)):
+        super().__init__()
+        self.input_modality = input_modality
+        dwi_tensor_input = DownSampleConv(6, 24, kernel=1, strides=1, padding=0)
+        bssfp_input = DownSampleConv(24, 24, kernel=1, strides=1, padding=0)
+        unet = BasicUNet(spatial_dims=3, in_channels=24, out_channels=6, features=features, dropout=dropout)
+        self.blocks = nn.ModuleDict({"dwi-tensor": dwi_tensor_input, "pc-bssfp": bssfp_input,
+                                     "bssfp": bssfp_input, "t1w": dwi_tensor_input, "unet": unet})
+
+    def forward(self, x):
+        head = self.blocks[self.input_modality]
+        a = head.forward_act(head._to_act(x))
+        z = self.blocks["unet"].forward_act(a)
+        return Fn.UnpackFn.apply(z, 6)

@@ -1,0 +1,328 @@
+"""Thin, autograd-free wrappers around the C ABI.  Tensors are NDHWC activations:
+shape (N, D, H, W, C), stride(-1) == 1, row stride ``ld`` = stride(-2) (>= C, lets a tensor be a
+channel slice of a wider buffer), dtype float32 (parity mode) or bfloat16 (throughput mode).
+PyTorch is used for device memory and streams only."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import DT_BF16, DT_F32
+
+_DT = {torch.float32: DT_F32, torch.bfloat16: DT_BF16}
+
+
+def round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.Mi355Error("unet_bssfp_amd runs on the GPU only (no CPU fallback): got a CPU tensor")
+
+
+def is_act(t: torch.Tensor) -> bool:
+    """True if t is a valid NDHWC activation view."""
+    if t.dim() != 5 or t.dtype not in _DT:
+        return False
+    n, d, h, w, c = t.shape
+    st = t.stride()
+    if c % 16 != 0 or st[4] != 1:
+        return False
+    ld = act_ld(t)
+    epv = 4 if t.dtype == torch.float32 else 8
+    if ld < c or ld % epv != 0 or t.data_ptr() % 16 != 0:
+        return False
+    exp = (d * h * w * ld, h * w * ld, w * ld, ld)
+    dims = (n, d, h, w)
+    return all(dims[i] == 1 or st[i] == exp[i] for i in range(4))
+
+
+def act_ld(t: torch.Tensor) -> int:
+    n, d, h, w, c = t.shape
+    st = t.stride()
+    if w > 1:
+        return st[3]
+    if h > 1:
+        return st[2]
+    if d > 1:
+        return st[1]
+    if n > 1:
+        return st[0]
+    return c
+
+
+def as_act(t: torch.Tensor) -> torch.Tensor:
+    return t if is_act(t) else t.contiguous()
+
+
+def new_act(n, d, h, w, c, dtype, device) -> torch.Tensor:
+    return torch.empty((n, d, h, w, c), dtype=dtype, device=device)
+
+
+# ------------------------------------------------------------------------------ pack / unpack
+def pack_ncdhw(src: torch.Tensor, dst: torch.Tensor, coff: int, zero_to: int):
+    """dst[..., coff:coff+C] = src (NCDHW f32 contiguous); dst[..., coff+C:zero_to] = 0."""
+    require_cuda(src, dst)
+    assert src.dtype == torch.float32 and src.is_contiguous() and src.dim() == 5
+    n, c = src.shape[:2]
+    v = src.shape[2] * src.shape[3] * src.shape[4]
+    lib = _lib.load()
+    _lib.check(lib.mi355_pack_ncdhw(src.data_ptr(), dst.data_ptr(), n, c, v, act_ld(dst), coff, zero_to,
+                                    _DT[dst.dtype], _stream()), "pack_ncdhw")
+
+
+def unpack_ncdhw(src: torch.Tensor, c: int, coff: int = 0) -> torch.Tensor:
+    require_cuda(src)
+    n, d, h, w, _ = src.shape
+    out = torch.empty((n, c, d, h, w), dtype=torch.float32, device=src.device)
+    lib = _lib.load()
+    _lib.check(lib.mi355_unpack_ncdhw(src.data_ptr(), out.data_ptr(), n, c, d * h * w, act_ld(src), coff,
+                                      _DT[src.dtype], _stream()), "unpack_ncdhw")
+    return out
+
+
+# ------------------------------------------------------------------------------ weights
+def weight_pack(src: torch.Tensor, cout: int, cin: int, ks: int, s_co: int, s_ci: int,
+                s_k: Sequence[int], tbase: Sequence[int], tstep: Sequence[int], dtype: torch.dtype,
+                cinp: Optional[int] = None) -> Tuple[torch.Tensor, int, int]:
+    """Returns (packed [cinp/16][ks^3][coutp][16], coutp, cinp)."""
+    require_cuda(src)
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    coutp = round_up(cout, 32)
+    cinp = round_up(cin, 16) if cinp is None else cinp
+    dst = torch.empty((cinp // 16, ks ** 3, coutp, 16), dtype=dtype, device=src.device)
+    d = _lib.WpackDesc()
+    d.src, d.dst = src.data_ptr(), dst.data_ptr()
+    d.cout, d.cin, d.coutp, d.cinp, d.ks = cout, cin, coutp, cinp, ks
+    d.s_co, d.s_ci = s_co, s_ci
+    d.s_k = (C.c_int64 * 3)(*s_k)
+    d.tbase = (C.c_int32 * 3)(*tbase)
+    d.tstep = (C.c_int32 * 3)(*tstep)
+    d.dtype = _DT[dtype]
+    _lib.check(_lib.load().mi355_weight_pack(C.byref(d), _stream()), "weight_pack")
+    return dst, coutp, cinp
+
+
+# ------------------------------------------------------------------------------ convolution
+def _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, stats):
+    d = _lib.ConvDesc()
+    n, di, hi, wi, c0 = x0.shape
+    d.x0, d.c0, d.ld0 = x0.data_ptr(), c0, act_ld(x0)
+    if x1 is not None:
+        assert x1.shape[:4] == x0.shape[:4] and x1.dtype == x0.dtype
+        d.x1, d.c1, d.ld1 = x1.data_ptr(), x1.shape[4], act_ld(x1)
+    else:
+        d.x1, d.c1, d.ld1 = None, 0, 0
+    d.n, d.di, d.hi, d.wi = n, di, hi, wi
+    d.do_, d.ho, d.wo = grid
+    d.ks, d.stride = ks, stride
+    d.pad = (C.c_int32 * 3)(*pad)
+    d.wp, d.coutp = wp.data_ptr(), coutp
+    d.bias = _ptr(bias)
+    d.y, d.ldy, d.cstore = out.data_ptr(), act_ld(out), out.shape[4]
+    d.dy, d.hy, d.wy = out.shape[1:4]
+    d.os = os
+    d.ooff = (C.c_int32 * 3)(*ooff)
+    d.stats_part = _ptr(stats)
+    d.dtype = _DT[x0.dtype]
+    return d
+
+
+def conv_num_tiles(x0, x1, wp, coutp, ks, stride, pad, out, grid, os=1, ooff=(0, 0, 0)) -> Tuple[int, int]:
+    d = _conv_desc(x0, x1, wp, coutp, None, ks, stride, pad, out, grid, os, ooff, None)
+    tiles, tps = C.c_int32(0), C.c_int32(0)
+    _lib.check(_lib.load().mi355_conv_num_tiles(C.byref(d), C.byref(tiles), C.byref(tps)), "conv_num_tiles")
+    return tiles.value, tps.value
+
+
+def conv_fwd(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os=1, ooff=(0, 0, 0), stats=None):
+    require_cuda(x0, x1, wp, bias, out, stats)
+    assert out.dtype == x0.dtype and wp.dtype == x0.dtype
+    assert bias is None or (bias.dtype == torch.float32 and bias.numel() >= coutp)
+    d = _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, stats)
+    _lib.check(_lib.load().mi355_conv_fwd(C.byref(d), _stream()), "conv_fwd")
+
+
+def conv_wgrad(x0, x1, g, grid, gs, goff, ks, stride, pad, dw, cout, cin, s_co, s_ci, s_k, tbase, tstep,
+               accumulate=False):
+    """dw (torch layout, f32) (+)= sum_p x[p*stride+tap-pad] * g[p*gs+goff]."""
+    require_cuda(x0, x1, g, dw)
+    assert dw.dtype == torch.float32 and g.dtype == x0.dtype
+    d = _lib.WgradDesc()
+    n, di, hi, wi, c0 = x0.shape
+    d.x0, d.c0, d.ld0 = x0.data_ptr(), c0, act_ld(x0)
+    if x1 is not None:
+        d.x1, d.c1, d.ld1 = x1.data_ptr(), x1.shape[4], act_ld(x1)
+    else:
+        d.x1, d.c1, d.ld1 = None, 0, 0
+    d.n, d.di, d.hi, d.wi = n, di, hi, wi
+    d.g, d.cg, d.ldg = g.data_ptr(), g.shape[4], act_ld(g)
+    d.do_, d.ho, d.wo = grid
+    d.gd, d.gh, d.gw = g.shape[1:4]
+    d.gs = gs
+    d.goff = (C.c_int32 * 3)(*goff)
+    d.ks, d.stride = ks, stride
+    d.pad = (C.c_int32 * 3)(*pad)
+    d.dw, d.cout, d.cin = dw.data_ptr(), cout, cin
+    d.s_co, d.s_ci = s_co, s_ci
+    d.s_k = (C.c_int64 * 3)(*s_k)
+    d.tbase = (C.c_int32 * 3)(*tbase)
+    d.tstep = (C.c_int32 * 3)(*tstep)
+    d.accumulate = 1 if accumulate else 0
+    d.dtype = _DT[x0.dtype]
+    lib = _lib.load()
+    need = lib.mi355_conv_wgrad_workspace(C.byref(d))
+    if need < 0:
+        _lib.check(-1, "conv_wgrad_workspace")
+    ws = torch.empty((need // 4,), dtype=torch.float32, device=x0.device)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), need
+    _lib.check(lib.mi355_conv_wgrad(C.byref(d), _stream()), "conv_wgrad")
+
+
+# ------------------------------------------------------------------------------ statistics / norm
+def channel_stats(x: torch.Tensor, groups: int) -> Tuple[torch.Tensor, int]:
+    """Partial {sum, sumsq} per channel: returns (part [groups*blocks][2][C], blocks_per_group)."""
+    require_cuda(x)
+    n, d, h, w, c = x.shape
+    rows = n * d * h * w
+    assert rows % groups == 0
+    rpg = rows // groups
+    lib = _lib.load()
+    bpg = lib.mi355_channel_stats_blocks(rpg)
+    part = torch.empty((groups * bpg, 2, c), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mi355_channel_stats(x.data_ptr(), act_ld(x), c, rpg, groups, part.data_ptr(), bpg,
+                                       _DT[x.dtype], _stream()), "channel_stats")
+    return part, bpg
+
+
+def norm_finalize(part, parts_per_group, groups, c, count, shift, eps, running_mean=None, running_var=None,
+                  momentum=0.0):
+    mean = torch.empty((groups, c), dtype=torch.float32, device=part.device)
+    rstd = torch.empty_like(mean)
+    _lib.check(_lib.load().mi355_norm_finalize(part.data_ptr(), parts_per_group, groups, c, count, _ptr(shift),
+                                               eps, mean.data_ptr(), rstd.data_ptr(), _ptr(running_mean),
+                                               _ptr(running_var), momentum, _stream()), "norm_finalize")
+    return mean, rstd
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    """Per-channel sum over all rows (f32 [C])."""
+    part, bpg = channel_stats(x, 1)
+    c = x.shape[4]
+    out = torch.empty((c,), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().mi355_colsum_finalize(part.data_ptr(), bpg, c, out.data_ptr(), _stream()), "colsum")
+    return out
+
+
+def _normact_desc(z, groups, mean, rstd, gamma, beta, slope, drop_p, seed):
+    d = _lib.NormActDesc()
+    n, dd, h, w, c = z.shape
+    rows = n * dd * h * w
+    d.z, d.ldz, d.c = z.data_ptr(), act_ld(z), c
+    d.rows_per_group, d.groups = rows // groups, groups
+    d.mean, d.rstd, d.gamma, d.beta = _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta)
+    d.slope, d.drop_p, d.seed = slope, drop_p, seed
+    d.dtype = _DT[z.dtype]
+    return d
+
+
+def normact_fwd(z, groups, mean, rstd, gamma, beta, slope, drop_p=0.0, seed=0, out=None):
+    require_cuda(z, mean, rstd, gamma, beta, out)
+    if out is None:
+        out = torch.empty(z.shape, dtype=z.dtype, device=z.device)
+    d = _normact_desc(z, groups, mean, rstd, gamma, beta, slope, drop_p, seed)
+    d.a, d.lda = out.data_ptr(), act_ld(out)
+    _lib.check(_lib.load().mi355_normact_fwd(C.byref(d), _stream()), "normact_fwd")
+    return out
+
+
+def normact_bwd(z, da, groups, mean, rstd, gamma, beta, slope, drop_p, seed, batch_stats, want_affine_grads):
+    """Returns (dz, dgamma, dbeta).  dgamma/dbeta are f32 [C] (None if there is no norm)."""
+    require_cuda(z, da)
+    lib = _lib.load()
+    n, dd, h, w, c = z.shape
+    rows = n * dd * h * w
+    d = _normact_desc(z, groups, mean, rstd, gamma, beta, slope, drop_p, seed)
+    d.da, d.ldda = da.data_ptr(), act_ld(da)
+    dz = torch.empty(z.shape, dtype=z.dtype, device=z.device)
+    d.dz, d.lddz = dz.data_ptr(), act_ld(dz)
+    d.batch_stats = 1 if batch_stats else 0
+    dgamma = dbeta = None
+    keep = []
+    if mean is not None and (batch_stats or want_affine_grads):
+        bpg = lib.mi355_channel_stats_blocks(rows // groups)
+        part = torch.empty((groups * bpg, 2, c), dtype=torch.float32, device=z.device)
+        d.part, d.blocks_per_group = part.data_ptr(), bpg
+        _lib.check(lib.mi355_normact_bwd_reduce(C.byref(d), _stream()), "normact_bwd_reduce")
+        sums = torch.empty((groups, 2, c), dtype=torch.float32, device=z.device)
+        dgamma = torch.empty((c,), dtype=torch.float32, device=z.device)
+        dbeta = torch.empty((c,), dtype=torch.float32, device=z.device)
+        _lib.check(lib.mi355_normact_bwd_finalize(part.data_ptr(), bpg, groups, c, sums.data_ptr(),
+                                                  dgamma.data_ptr(), dbeta.data_ptr(), _stream()),
+                   "normact_bwd_finalize")
+        d.sums = sums.data_ptr()
+        keep += [part, sums]
+    _lib.check(lib.mi355_normact_bwd_apply(C.byref(d), _stream()), "normact_bwd_apply")
+    return dz, dgamma, dbeta
+
+
+# ------------------------------------------------------------------------------ pooling
+def maxpool2_fwd(x: torch.Tensor) -> torch.Tensor:
+    require_cuda(x)
+    n, d, h, w, c = x.shape
+    y = torch.empty((n, d // 2, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().mi355_maxpool2_fwd(x.data_ptr(), act_ld(x), y.data_ptr(), act_ld(y), n, c, d, h, w,
+                                              _DT[x.dtype], _stream()), "maxpool2_fwd")
+    return y
+
+
+def maxpool2_bwd(x, y, dy) -> torch.Tensor:
+    require_cuda(x, y, dy)
+    n, d, h, w, c = x.shape
+    dx = torch.empty((n, d, h, w, c), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().mi355_maxpool2_bwd(x.data_ptr(), act_ld(x), y.data_ptr(), act_ld(y), dy.data_ptr(),
+                                              act_ld(dy), dx.data_ptr(), act_ld(dx), n, c, d, h, w,
+                                              _DT[x.dtype], _stream()), "maxpool2_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------------------ loss / optimiser
+def l1_fwd(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    require_cuda(a, b)
+    assert a.dtype == b.dtype == torch.float32 and a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+    lib = _lib.load()
+    cnt = a.numel()
+    partials = torch.empty((lib.mi355_l1_blocks(cnt),), dtype=torch.float32, device=a.device)
+    out = torch.empty((), dtype=torch.float32, device=a.device)
+    _lib.check(lib.mi355_l1_fwd(a.data_ptr(), b.data_ptr(), cnt, partials.data_ptr(), out.data_ptr(), _stream()),
+               "l1_fwd")
+    return out
+
+
+def l1_bwd(a, b, gscale: torch.Tensor) -> torch.Tensor:
+    require_cuda(a, b, gscale)
+    da = torch.empty_like(a)
+    gs = gscale.to(torch.float32).reshape(1).contiguous()
+    _lib.check(_lib.load().mi355_l1_bwd(a.data_ptr(), b.data_ptr(), a.numel(), gs.data_ptr(), da.data_ptr(),
+                                        _stream()), "l1_bwd")
+    return da
+
+
+def mfma_selftest(device) -> Tuple[torch.Tensor, torch.Tensor]:
+    a = torch.zeros(1024, dtype=torch.float32, device=device)
+    b = torch.zeros(1024, dtype=torch.float32, device=device)
+    _lib.check(_lib.load().mi355_mfma_selftest(a.data_ptr(), b.data_ptr(), _stream()), "mfma_selftest")
+    return a.view(32, 32), b.view(32, 32)
