@@ -109,6 +109,9 @@ typedef struct mi355_conv_desc {
   int32_t dtype;
 } mi355_conv_desc;
 int mi355_conv_fwd(const mi355_conv_desc* d, void* stream);
+/* which kernel instance mi355_conv_fwd() will launch for this descriptor (for profiling tools):
+ * 1000*halo + 100*tile_shape + 10*voxel_subtiles_per_wave + cout_subtiles_per_wave, <0 on error */
+int mi355_conv_plan_id(const mi355_conv_desc* d);
 /* number of spatial tiles (= rows of stats_part) and tiles per sample (0 if tiles span samples) */
 int mi355_conv_num_tiles(const mi355_conv_desc* d, int32_t* tiles, int32_t* tiles_per_sample);
 

@@ -59,6 +59,7 @@ _SIGNATURES = {
     "mi355_unpack_ncdhw": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _i32, _vp]),
     "mi355_weight_pack": (C.c_int, [C.POINTER(WpackDesc), _vp]),
     "mi355_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), _vp]),
+    "mi355_conv_plan_id": (C.c_int, [C.POINTER(ConvDesc)]),
     "mi355_conv_num_tiles": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(_i32), C.POINTER(_i32)]),
     "mi355_conv_wgrad_workspace": (_i64, [C.POINTER(WgradDesc)]),
     "mi355_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc), _vp]),

@@ -96,6 +96,13 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int mi355_conv_plan_id(const mi355_conv_desc* d) {
+  Plan p;
+  int rc = make_plan(d, &p);
+  if (rc) return rc;
+  return 1000 * (p.halo ? 1 : 0) + 100 * p.shape + 10 * p.vt + p.ct;
+}
+
 extern "C" int mi355_conv_num_tiles(const mi355_conv_desc* d, int32_t* tiles, int32_t* tiles_per_sample) {
   Plan p;
   int rc = make_plan(d, &p);

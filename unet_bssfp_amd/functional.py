@@ -178,13 +178,15 @@ class ConvFn(Function):
             if want_stats:
                 tiles, _ = ops.conv_num_tiles(x0, x1, wp, coutp, spec.ks, spec.stride, pad3, out, (do_, ho, wo))
                 part = torch.empty((tiles, 2, coutp), dtype=torch.float32, device=dev)
-            ops.conv_fwd(x0, x1, wp, coutp, bp, spec.ks, spec.stride, pad3, out, (do_, ho, wo), stats=part)
+            ops.conv_fwd(x0, x1, wp, coutp, bp, spec.ks, spec.stride, pad3, out, (do_, ho, wo), stats=part,
+                         real=(spec.cin, spec.cout))
         else:
             assert x1 is None and not want_stats
             for cls in CLASSES8:
                 wp, coutp, _ = spec.w_deconv_fwd(weight, dtype, c0, cls)
                 bp = _padded(bias, coutp)
-                ops.conv_fwd(x0, None, wp, coutp, bp, 1, 1, (0, 0, 0), out, (di, hi, wi), os=2, ooff=cls)
+                ops.conv_fwd(x0, None, wp, coutp, bp, 1, 1, (0, 0, 0), out, (di, hi, wi), os=2, ooff=cls,
+                             real=(spec.cin, spec.cout))
         ctx.save_for_backward(x0, x1, weight)
         ctx.spec = spec
         ctx.has_bias = bias is not None
@@ -211,17 +213,19 @@ class ConvFn(Function):
             dxc = ops.new_act(n, di, hi, wi, c0 + c1, dtype, dev)
             if spec.kind == "conv" and spec.stride == 1:
                 wp, coutp, _ = spec.w_dgrad_s1(weight, dtype, cg, c0 + c1)
-                ops.conv_fwd(dz, None, wp, coutp, None, k, 1, (k - 1 - spec.pad,) * 3, dxc, (di, hi, wi))
+                ops.conv_fwd(dz, None, wp, coutp, None, k, 1, (k - 1 - spec.pad,) * 3, dxc, (di, hi, wi),
+                             real=(spec.cout, spec.cin))
             elif spec.kind == "conv":
                 if not (k == 4 and spec.stride == 2 and spec.pad == 1 and di % 2 == 0 and hi % 2 == 0 and wi % 2 == 0):
                     raise NotImplementedError("strided data gradient is implemented for k4 s2 p1 on even extents")
                 for cls in CLASSES8:
                     wp, coutp, _ = spec.w_dgrad_s2(weight, dtype, cg, cls)
                     pad3 = tuple(1 if p == 0 else 0 for p in cls)
-                    ops.conv_fwd(dz, None, wp, coutp, None, 2, 1, pad3, dxc, (di // 2, hi // 2, wi // 2), os=2, ooff=cls)
+                    ops.conv_fwd(dz, None, wp, coutp, None, 2, 1, pad3, dxc, (di // 2, hi // 2, wi // 2), os=2, ooff=cls,
+                                 real=(spec.cout, spec.cin))
             else:
                 wp, coutp, _ = spec.w_deconv_dgrad(weight, dtype, cg)
-                ops.conv_fwd(dz, None, wp, coutp, None, 2, 2, (0, 0, 0), dxc, (di, hi, wi))
+                ops.conv_fwd(dz, None, wp, coutp, None, 2, 2, (0, 0, 0), dxc, (di, hi, wi), real=(spec.cout, spec.cin))
             dx0 = dxc[..., :c0] if c1 else dxc
             dx1 = dxc[..., c0:] if c1 else None
         if ctx.needs_input_grad[2]:

@@ -148,12 +148,21 @@ def conv_num_tiles(x0, x1, wp, coutp, ks, stride, pad, out, grid, os=1, ooff=(0,
     return tiles.value, tps.value
 
 
-def conv_fwd(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os=1, ooff=(0, 0, 0), stats=None):
+# Optional launch probe (bench.py): called as probe(plan_id, desc, (cin, cout) real GEMM extents) and returns None or a callable
+# that is invoked right after the launch (used to bracket one kernel family with HIP events).
+CONV_PROBE = None
+
+
+def conv_fwd(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os=1, ooff=(0, 0, 0), stats=None, real=None):
     require_cuda(x0, x1, wp, bias, out, stats)
     assert out.dtype == x0.dtype and wp.dtype == x0.dtype
     assert bias is None or (bias.dtype == torch.float32 and bias.numel() >= coutp)
     d = _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, stats)
-    _lib.check(_lib.load().mi355_conv_fwd(C.byref(d), _stream()), "conv_fwd")
+    lib = _lib.load()
+    after = CONV_PROBE(lib.mi355_conv_plan_id(C.byref(d)), d, real) if CONV_PROBE is not None else None
+    _lib.check(lib.mi355_conv_fwd(C.byref(d), _stream()), "conv_fwd")
+    if after is not None:
+        after()
 
 
 def conv_wgrad(x0, x1, g, grid, gs, goff, ks, stride, pad, dw, cout, cin, s_co, s_ci, s_k, tbase, tstep,
