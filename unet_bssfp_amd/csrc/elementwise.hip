@@ -121,20 +121,56 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict_
       out, out + c);
 }
 
-__global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restrict__ part, int ppg, int c,
-                                                            long long count, const float* __restrict__ shift,
-                                                            float eps, float* __restrict__ mean,
-                                                            float* __restrict__ rstd, float* running_mean,
-                                                            float* running_var, float momentum) {
-  const int g = blockIdx.y;
-  const int ch = blockIdx.x * 256 + threadIdx.x;
-  if (ch >= c) return;
-  double s1 = 0.0, s2 = 0.0;
-  const float* p = part + (long long)g * ppg * 2 * c;
-  for (int k = 0; k < ppg; ++k) {
-    s1 += (double)p[(long long)k * 2 * c + ch];
-    s2 += (double)p[(long long)k * 2 * c + c + ch];
+// Sum of per-block/per-tile partials part[k][2][c] over k for 8 channels per workgroup:
+// 1024 threads = 8 channels x 128 partial lanes, f64 accumulate, fixed-order LDS tree (deterministic).
+// The totals of channel ch0 + (tid & 7) are returned to the threads with tid < 8.
+__device__ __forceinline__ void block_sum_parts(const float* __restrict__ part, int nparts, int c, int ch0,
+                                                double& t0, double& t1) {
+  __shared__ double red[128][8][2];
+  const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int ch = ch0 + cl;
+  double s0 = 0.0, s1 = 0.0;
+  if (ch < c) {
+    int k = pl;
+    for (; k + 384 < nparts; k += 512) {
+      const float a0 = part[(long long)k * 2 * c + ch], b0 = part[(long long)k * 2 * c + c + ch];
+      const float a1 = part[(long long)(k + 128) * 2 * c + ch], b1 = part[(long long)(k + 128) * 2 * c + c + ch];
+      const float a2 = part[(long long)(k + 256) * 2 * c + ch], b2 = part[(long long)(k + 256) * 2 * c + c + ch];
+      const float a3 = part[(long long)(k + 384) * 2 * c + ch], b3 = part[(long long)(k + 384) * 2 * c + c + ch];
+      s0 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+      s1 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+    }
+    for (; k < nparts; k += 128) {
+      s0 += (double)part[(long long)k * 2 * c + ch];
+      s1 += (double)part[(long long)k * 2 * c + c + ch];
+    }
   }
+  red[pl][cl][0] = s0;
+  red[pl][cl][1] = s1;
+  __syncthreads();
+  for (int o = 64; o > 0; o >>= 1) {
+    if (pl < o) {
+      red[pl][cl][0] += red[pl + o][cl][0];
+      red[pl][cl][1] += red[pl + o][cl][1];
+    }
+    __syncthreads();
+  }
+  t0 = red[0][cl][0];
+  t1 = red[0][cl][1];
+  __syncthreads();      // red is reused by the caller's next call
+}
+
+__global__ __launch_bounds__(1024) void norm_finalize_kernel(const float* __restrict__ part, int ppg, int c,
+                                                             long long count, const float* __restrict__ shift,
+                                                             float eps, float* __restrict__ mean,
+                                                             float* __restrict__ rstd, float* running_mean,
+                                                             float* running_var, float momentum) {
+  const int g = blockIdx.y;
+  const int ch0 = blockIdx.x * 8;
+  double s1, s2;
+  block_sum_parts(part + (long long)g * ppg * 2 * c, ppg, c, ch0, s1, s2);
+  const int ch = ch0 + (int)threadIdx.x;
+  if (threadIdx.x >= 8 || ch >= c) return;
   const double m = s1 / (double)count;
   double var = s2 / (double)count - m * m;
   if (var < 0.0) var = 0.0;
@@ -148,13 +184,13 @@ __global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restr
   }
 }
 
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int parts, int c,
-                                                              float* __restrict__ out) {
-  const int ch = blockIdx.x * 256 + threadIdx.x;
-  if (ch >= c) return;
-  double s = 0.0;
-  for (int k = 0; k < parts; ++k) s += (double)part[(long long)k * 2 * c + ch];
-  out[ch] = (float)s;
+__global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ part, int parts, int c,
+                                                               float* __restrict__ out) {
+  const int ch0 = blockIdx.x * 8;
+  double s0, s1;
+  block_sum_parts(part, parts, c, ch0, s0, s1);
+  const int ch = ch0 + (int)threadIdx.x;
+  if (threadIdx.x < 8 && ch < c) out[ch] = (float)s0;
 }
 
 // ------------------------------------------------------------------ norm + dropout + LeakyReLU
@@ -271,26 +307,27 @@ __global__ __launch_bounds__(256) void normact_bwd_reduce_kernel(const NormActAr
       out, out + q.c);
 }
 
-__global__ __launch_bounds__(256) void normact_bwd_finalize_kernel(const float* __restrict__ part, int bpg,
-                                                                   int groups, int c, float* __restrict__ sums,
-                                                                   float* dgamma, float* dbeta) {
-  const int ch = blockIdx.x * 256 + threadIdx.x;
-  if (ch >= c) return;
+__global__ __launch_bounds__(1024) void normact_bwd_finalize_kernel(const float* __restrict__ part, int bpg,
+                                                                    int groups, int c, float* __restrict__ sums,
+                                                                    float* dgamma, float* dbeta) {
+  const int ch0 = blockIdx.x * 8;
+  const int ch = ch0 + (int)threadIdx.x;
+  const bool owner = threadIdx.x < 8 && ch < c;
   double tg = 0.0, tb = 0.0;
   for (int g = 0; g < groups; ++g) {
-    double s0 = 0.0, s1 = 0.0;
-    const float* p = part + (long long)g * bpg * 2 * c;
-    for (int k = 0; k < bpg; ++k) {
-      s0 += (double)p[(long long)k * 2 * c + ch];
-      s1 += (double)p[(long long)k * 2 * c + c + ch];
+    double s0, s1;
+    block_sum_parts(part + (long long)g * bpg * 2 * c, bpg, c, ch0, s0, s1);
+    if (owner) {
+      sums[((long long)g * 2 + 0) * c + ch] = (float)s0;
+      sums[((long long)g * 2 + 1) * c + ch] = (float)s1;
+      tb += s0;
+      tg += s1;
     }
-    sums[((long long)g * 2 + 0) * c + ch] = (float)s0;
-    sums[((long long)g * 2 + 1) * c + ch] = (float)s1;
-    tb += s0;
-    tg += s1;
   }
-  if (dgamma) dgamma[ch] = (float)tg;
-  if (dbeta) dbeta[ch] = (float)tb;
+  if (owner) {
+    if (dgamma) dgamma[ch] = (float)tg;
+    if (dbeta) dbeta[ch] = (float)tb;
+  }
 }
 
 template <typename T>
@@ -584,14 +621,14 @@ int mi355_norm_finalize(const float* part, int32_t parts_per_group, int32_t grou
                         float* running_var, float momentum, void* stream) {
   MI355_REQUIRE(part && mean && rstd && parts_per_group > 0 && groups > 0 && c > 0 && count_per_group > 0, "norm_finalize: bad argument");
   MI355_REQUIRE(!running_mean || (running_var && groups == 1), "norm_finalize: running stats need groups == 1");
-  hipLaunchKernelGGL(norm_finalize_kernel, dim3((c + 255) / 256, groups), dim3(256), 0, (hipStream_t)stream, part,
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3((c + 7) / 8, groups), dim3(1024), 0, (hipStream_t)stream, part,
                      parts_per_group, c, (long long)count_per_group, shift, eps, mean, rstd, running_mean, running_var, momentum);
   return mi355_check_launch("norm_finalize");
 }
 
 int mi355_colsum_finalize(const float* part, int32_t parts, int32_t c, float* out, void* stream) {
   MI355_REQUIRE(part && out && parts > 0 && c > 0, "colsum_finalize: bad argument");
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, parts, c, out);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((c + 7) / 8), dim3(1024), 0, (hipStream_t)stream, part, parts, c, out);
   return mi355_check_launch("colsum_finalize");
 }
 
@@ -648,7 +685,7 @@ int mi355_normact_bwd_reduce(const mi355_normact_desc* d, void* stream) {
 int mi355_normact_bwd_finalize(const float* part, int32_t blocks_per_group, int32_t groups, int32_t c, float* sums,
                                float* dgamma, float* dbeta, void* stream) {
   MI355_REQUIRE(part && sums && blocks_per_group > 0 && groups > 0 && c > 0, "normact_bwd_finalize: bad argument");
-  hipLaunchKernelGGL(normact_bwd_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, part,
+  hipLaunchKernelGGL(normact_bwd_finalize_kernel, dim3((c + 7) / 8), dim3(1024), 0, (hipStream_t)stream, part,
                      blocks_per_group, groups, c, sums, dgamma, dbeta);
   return mi355_check_launch("normact_bwd_finalize");
 }

@@ -110,23 +110,164 @@ struct WreduceArgs {
   int accumulate;
 };
 
+// 256 threads = 32 consecutive elements x 8 slab lanes; fixed-order LDS combine (deterministic)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WreduceArgs a) {
+  __shared__ float red[8][32];
   const long long per = (long long)a.ntaps * a.cinp * a.coutp;
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= per) return;
+  const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const long long idx = (long long)blockIdx.x * 32 + e;
+  float s = 0.f;
+  if (idx < per) {
+    int k = sl;
+    for (; k + 24 < a.nslabs; k += 32) {
+      const float v0 = a.slab[(long long)k * per + idx], v1 = a.slab[(long long)(k + 8) * per + idx];
+      const float v2 = a.slab[(long long)(k + 16) * per + idx], v3 = a.slab[(long long)(k + 24) * per + idx];
+      s += (v0 + v1) + (v2 + v3);
+    }
+    for (; k < a.nslabs; k += 8) s += a.slab[(long long)k * per + idx];
+  }
+  red[sl][e] = s;
+  __syncthreads();
+  if (sl != 0 || idx >= per) return;
+#pragma unroll
+  for (int q = 1; q < 8; ++q) s += red[q][e];
   const int co = (int)(idx % a.coutp);
   const int ci = (int)((idx / a.coutp) % a.cinp);
   const int tap = (int)(idx / ((long long)a.coutp * a.cinp));
   if (co >= a.cout || ci >= a.cin) return;
-  float s = 0.f;
-  for (int k = 0; k < a.nslabs; ++k) s += a.slab[(long long)k * per + idx];
   const int td = tap / (a.ks * a.ks), th = (tap / a.ks) % a.ks, tw = tap % a.ks;
   const long long dst = co * a.s_co + ci * a.s_ci + (a.tb0 + a.ts0 * td) * a.s_k0 +
                         (a.tb1 + a.ts1 * th) * a.s_k1 + (a.tb2 + a.ts2 * tw) * a.s_k2;
   if (a.accumulate) a.dw[dst] += s; else a.dw[dst] = s;
 }
 
-struct WPlan { int ks, tpw, tap_groups, ci_tiles, co_tiles, splits, cinp32, coutp32; long long rows; };
+
+// ------------------------------------------------------------------------------------------
+// bf16 3x3x3 stride-1 weight gradient on v_mfma_f32_32x32x16_bf16.
+// D[ci][co] += sum_k A[ci][k] * B[k][co], k = 16 consecutive W positions.  Both operands are
+// k-strided in memory ([position][channel] rows of 64 B), so the fragments are fetched with the
+// gfx950 transposed LDS read ds_read_b64_tr_b16 (4 positions x 16 channels per 16-lane group, two
+// reads per fragment); 4 consecutive positions x 32 channels = 256 contiguous bytes per 32-lane
+// half => conflict-free.  A workgroup stages the x halo and the g tile of one 32x32 (ci, co)
+// block once and its 4 waves share them, each owning 7 (6) of the 27 taps; the g fragment is
+// reused across a wave's taps.  Accumulators live across all tiles of the workgroup's split.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ s16x4 lds_tr16(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+__device__ __forceinline__ bf16x8 frag_tr(const char* p) {
+  const s16x4 lo = lds_tr16(p), hi = lds_tr16(p + 4 * 64);
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <int TD, int TH, int TW>
+__global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const WgradArgs a, int tiles_d, int tiles_h,
+                                                                int tiles_w, int ntiles) {
+  constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
+  constexpr int XROWS = HD * HH * HW, GROWS = TD * TH * TW;
+  constexpr int NPX = (XROWS * 4 + 255) / 256, NPG = (GROWS * 4 + 255) / 256;
+  constexpr int SEGS = TW / 16;
+  static_assert(TW % 16 == 0, "tile width");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* xs = smem;
+  char* gsm = smem + XROWS * 64;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int ci_base = blockIdx.y * 32, co_base = blockIdx.z * 32;
+  const bool first = ci_base < a.c0;
+  const char* xsrc = first ? a.x0 : a.x1;
+  const long long ldx = first ? a.ld0 : a.ld1;
+  const int cix = first ? ci_base : ci_base - a.c0;
+  const int cx_lim = (first ? a.c0 : a.c1) - cix;      // channels of this source left from cix
+  const int cg_lim = a.cg - co_base;
+
+  int toff[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int tap = wave + 4 * i;
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    toff[i] = tap < 27 ? ((kd * HH + kh) * HW + kw) * 64 : 0;
+  }
+  const int gi = lane & 15;
+  const int lane_off = (8 * h + (gi >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (gi & 3)) * 2;
+
+  f32x16 acc[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int t = tile;
+    const int tw_i = t % tiles_w; t /= tiles_w;
+    const int th_i = t % tiles_h; t /= tiles_h;
+    const int td_i = t % tiles_d;
+    const int n = t / tiles_d;
+    const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
+    uint4 sx[NPX];
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+      const int p = tid + i * 256;
+      const int row = p >> 2, part = p & 3;
+      const int hw = row % HW, hh = (row / HW) % HH, hd = row / (HW * HH);
+      const int gd = d0 + hd - a.pd, gh = h0 + hh - a.ph, gw = w0 + hw - a.pw;
+      const bool ok = p < XROWS * 4 && part * 8 < cx_lim && gd >= 0 && gd < a.di && gh >= 0 && gh < a.hi && gw >= 0 && gw < a.wi;
+      sx[i] = ok ? *reinterpret_cast<const uint4*>(xsrc + (((((long long)n * a.di + gd) * a.hi + gh) * a.wi + gw) * ldx + cix + part * 8) * 2)
+                 : make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();                      // every wave finished reading the previous tile
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+      const int p = tid + i * 256;
+      if (p < XROWS * 4) *reinterpret_cast<uint4*>(xs + p * 16) = sx[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NPG; ++i) {
+      const int p = tid + i * 256;
+      const int row = p >> 2, part = p & 3;
+      const int sw = row % TW, sh = (row / TW) % TH, sd = row / (TW * TH);
+      const int gd = d0 + sd, gh = h0 + sh, gw = w0 + sw;
+      const bool ok = p < GROWS * 4 && part * 8 < cg_lim && gd < a.do_ && gh < a.ho && gw < a.wo;
+      const uint4 v = ok ? *reinterpret_cast<const uint4*>(a.g + (((((long long)n * a.gd + gd) * a.gh + gh) * a.gw + gw) * (long long)a.ldg + co_base + part * 8) * 2)
+                         : make_uint4(0, 0, 0, 0);
+      if (p < GROWS * 4) *reinterpret_cast<uint4*>(gsm + p * 16) = v;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int kg = 0; kg < TD * TH * SEGS; ++kg) {
+      const int seg = kg % SEGS, sh = (kg / SEGS) % TH, sd = kg / (SEGS * TH);
+      const char* gp = gsm + ((sd * TH + sh) * TW + seg * 16) * 64 + lane_off;
+      const char* xp = xs + ((sd * HH + sh) * HW + seg * 16) * 64 + lane_off;
+      const bf16x8 b = frag_tr(gp);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const bf16x8 af = frag_tr(xp + toff[i]);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b, acc[i], 0, 0, 0);
+      }
+    }
+  }
+  float* sl = a.slab + ((long long)blockIdx.x * 27) * a.cinp * a.coutp;
+  const int co = co_base + r;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int tap = wave + 4 * i;
+    if (tap < 27) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int row = ci_base + acc_row(j, h);
+        sl[((long long)tap * a.cinp + row) * a.coutp + co] = acc[i][j];
+      }
+    }
+  }
+}
+
+struct WPlan { int ks, tpw, tap_groups, ci_tiles, co_tiles, splits, cinp32, coutp32; long long rows;
+               bool fast; int shape, tiles_d, tiles_h, tiles_w, ntiles, nslabs; };
+
+const int kWTD[2] = {2, 2}, kWTH[2] = {4, 8}, kWTW[2] = {32, 16};
 
 int wplan(const mi355_wgrad_desc* d, WPlan* p) {
   MI355_REQUIRE(d && d->x0 && d->g && d->dw, "wgrad: null pointer");
@@ -153,6 +294,24 @@ int wplan(const mi355_wgrad_desc* d, WPlan* p) {
   const long long slab_bytes = (long long)nt * p->cinp32 * p->coutp32 * 4;
   while (s > 1 && s * 4 * slab_bytes > (256ll << 20)) s /= 2;
   p->splits = (int)s;
+  p->nslabs = p->splits * 4;
+  // fast path: bf16, 3x3x3 stride 1, g on the same grid as the outputs
+  p->fast = d->dtype == MI355_DT_BF16 && d->ks == 3 && d->stride == 1 && d->gs == 1 && d->goff[0] == 0 &&
+            d->goff[1] == 0 && d->goff[2] == 0 && d->gd == d->do_ && d->gh == d->ho && d->gw == d->wo &&
+            d->ld0 % 8 == 0 && (d->c1 == 0 || d->ld1 % 8 == 0) && d->ldg % 8 == 0;
+  if (p->fast) {
+    p->shape = d->wo > 16 ? 0 : 1;
+    p->tiles_d = ceil_div(d->do_, kWTD[p->shape]);
+    p->tiles_h = ceil_div(d->ho, kWTH[p->shape]);
+    p->tiles_w = ceil_div(d->wo, kWTW[p->shape]);
+    p->ntiles = p->tiles_d * p->tiles_h * p->tiles_w * d->n;
+    long long sp = 512 / ((long long)p->ci_tiles * p->co_tiles);
+    if (sp < 1) sp = 1;
+    if (sp > p->ntiles) sp = p->ntiles;
+    while (sp > 1 && sp * slab_bytes > (256ll << 20)) sp /= 2;
+    p->splits = (int)sp;
+    p->nslabs = p->splits;
+  }
   return MI355_OK;
 }
 
@@ -172,7 +331,7 @@ void launch_wgrad(const WgradArgs& a, const WPlan& p, hipStream_t st) {
 extern "C" int64_t mi355_conv_wgrad_workspace(const mi355_wgrad_desc* d) {
   WPlan p;
   if (wplan(d, &p)) return -1;
-  return (int64_t)p.splits * 4 * p.ks * p.ks * p.ks * p.cinp32 * p.coutp32 * 4;
+  return (int64_t)p.nslabs * p.ks * p.ks * p.ks * p.cinp32 * p.coutp32 * 4;
 }
 
 extern "C" int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream) {
@@ -196,11 +355,21 @@ extern "C" int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream) {
   a.stride = d->stride; a.pd = d->pad[0]; a.ph = d->pad[1]; a.pw = d->pad[2];
   a.slab = d->workspace; a.cinp = p.cinp32; a.coutp = p.coutp32;
   a.splits = p.splits; a.tap_groups = p.tap_groups; a.rows = p.rows;
-  if (d->dtype == MI355_DT_F32) launch_wgrad<float>(a, p, st); else launch_wgrad<bf16_t>(a, p, st);
+  if (p.fast) {
+    dim3 grid(p.splits, p.ci_tiles, p.co_tiles), block(256);
+    if (p.shape == 0) {
+      constexpr int lds = (4 * 6 * 34 + 2 * 4 * 32) * 64;
+      wgrad_k3_bf16_kernel<2, 4, 32><<<grid, block, lds, st>>>(a, p.tiles_d, p.tiles_h, p.tiles_w, p.ntiles);
+    } else {
+      constexpr int lds = (4 * 10 * 18 + 2 * 8 * 16) * 64;
+      wgrad_k3_bf16_kernel<2, 8, 16><<<grid, block, lds, st>>>(a, p.tiles_d, p.tiles_h, p.tiles_w, p.ntiles);
+    }
+  } else if (d->dtype == MI355_DT_F32) launch_wgrad<float>(a, p, st);
+  else launch_wgrad<bf16_t>(a, p, st);
   rc = mi355_check_launch("conv_wgrad");
   if (rc) return rc;
   WreduceArgs q;
-  q.slab = d->workspace; q.nslabs = p.splits * 4; q.ks = d->ks; q.ntaps = d->ks * d->ks * d->ks;
+  q.slab = d->workspace; q.nslabs = p.nslabs; q.ks = d->ks; q.ntaps = d->ks * d->ks * d->ks;
   q.cinp = p.cinp32; q.coutp = p.coutp32;
   q.dw = d->dw; q.cout = d->cout; q.cin = d->cin;
   q.s_co = d->s_co; q.s_ci = d->s_ci; q.s_k0 = d->s_k[0]; q.s_k1 = d->s_k[1]; q.s_k2 = d->s_k[2];
@@ -208,6 +377,6 @@ extern "C" int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream) {
   q.ts0 = d->tstep[0]; q.ts1 = d->tstep[1]; q.ts2 = d->tstep[2];
   q.accumulate = d->accumulate;
   const long long per = (long long)q.ntaps * q.cinp * q.coutp;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, q);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 31) / 32)), dim3(256), 0, st, q);
   return mi355_check_launch("wgrad_reduce");
 }
