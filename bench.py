@@ -35,7 +35,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
-DOMINANT_PLAN = 1021          # halo kernel, tile 2x4x32, 2 voxel subtiles/wave, 1 cout subtile/wave
+# dominant kernel family = full-resolution 3x3x3 implicit GEMM with 32 output channels
+# plan id = 1000*halo + 100*tile_shape + 10*voxel_subtiles_per_wave + cout_subtiles_per_wave
+DOMINANT_PLAN = {"bf16": (1341, "conv_k3_halo_kernel<bf16_t,4,4,32,1>"), "f32": (1021, "conv_k3_halo_kernel<float,2,4,32,1>")}
 
 
 def parse():
@@ -153,7 +155,7 @@ def main():
             gen_opt.step()
             gen_opt.zero_grad()
 
-    probe = KernelProbe(DOMINANT_PLAN)
+    probe = KernelProbe(DOMINANT_PLAN[a.dtype][0])
     if not a.no_probe:
         ops.CONV_PROBE = probe
 
@@ -199,7 +201,7 @@ def main():
             ach = s["flops"] / (s["total_ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
                                "frac": ach / PEAK_TFLOPS[a.dtype], "traffic": None,
-                               "kernel": f"conv_k3_halo_kernel<{'bf16_t' if a.dtype == 'bf16' else 'float'},2,4,32,1>",
+                               "kernel": DOMINANT_PLAN[a.dtype][1],
                                "launches": s["launches"], "avg_launch_ms": s["avg_ms"],
                                "share_of_step": s["total_ms"] / (dt * 1e3)}
         if world == 1 and not a.no_cpu_baseline:

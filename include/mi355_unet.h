@@ -57,6 +57,16 @@ int mi355_pack_ncdhw(const float* src, void* dst, int32_t n, int32_t c, int64_t 
                      int32_t ld, int32_t coff, int32_t zero_to, int32_t dtype, void* stream);
 int mi355_unpack_ncdhw(const void* src, float* dst, int32_t n, int32_t c, int64_t v,
                        int32_t ld, int32_t coff, int32_t dtype, void* stream);
+/* Space-to-depth variants (PatchGAN path).  For a plain tensor a (N,D,H,W,C), even extents,
+ *   S(a)[n, jd, jh, jw, blk*cblk + c] = a[n, 2jd+bd-1, 2jh+bh-1, 2jw+bw-1, c],  blk = 4bd+2bh+bw,
+ * extents (D/2+1, H/2+1, W/2+1), 8*cblk channels per row (out-of-range cells stay zero: the caller
+ * zero-fills S once).  The reference's Conv3d(k=4, s=2, p=1) (src/model.py:44,50) on a equals a
+ * dense k=2, s=1, p=0 convolution on S(a), so the PatchGAN runs on the stride-1 kernels.
+ * pack:  writes channels [coff, coff+c) (zeros up to zero_to) of every block;  unpack: reads them. */
+int mi355_pack_ncdhw_s2d(const float* src, void* dst, int32_t n, int32_t c, int32_t d, int32_t h, int32_t w,
+                         int32_t cblk, int32_t ld, int32_t coff, int32_t zero_to, int32_t dtype, void* stream);
+int mi355_unpack_ncdhw_s2d(const void* src, float* dst, int32_t n, int32_t c, int32_t d, int32_t h, int32_t w,
+                           int32_t cblk, int32_t ld, int32_t coff, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Weight packing.  Reference weights are torch layout: Conv3d (Cout,Cin,k,k,k) f32,
@@ -77,6 +87,10 @@ typedef struct mi355_wpack_desc {
   int64_t s_k[3];
   int32_t tbase[3], tstep[3];
   int32_t dtype;
+  /* space-to-depth operands (mi355_pack_ncdhw_s2d): s2d_mode 1 = the GEMM cin index is
+   * blk*s2d_cp + c (cin = real channels per block, cinp = 8*s2d_cp), 2 = the GEMM cout index is;
+   * the block's parity bits (bd,bh,bw) are added to the source tap coordinates. 0 = off. */
+  int32_t s2d_mode, s2d_cp;
 } mi355_wpack_desc;
 int mi355_weight_pack(const mi355_wpack_desc* d, void* stream);
 
@@ -139,6 +153,7 @@ typedef struct mi355_wgrad_desc {
   int32_t tbase[3], tstep[3];
   int32_t accumulate;                       /* 0: overwrite, 1: add into dw */
   int32_t dtype;
+  int32_t s2d_cp;                           /* >0: x is a space-to-depth tensor, ci = blk*s2d_cp + c (cin = real c) */
 } mi355_wgrad_desc;
 int64_t mi355_conv_wgrad_workspace(const mi355_wgrad_desc* d);
 int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream);
@@ -179,6 +194,11 @@ typedef struct mi355_normact_desc {
   int32_t blocks_per_group;
   const float* sums;                      /* [groups][2][c] reduced sums (bwd_apply) */
   int32_t batch_stats;                    /* 1: subtract mean terms (train), 0: eval-mode norm */
+  /* space-to-depth coupling with the next k4 s2 convolution (see mi355_pack_ncdhw_s2d):
+   * s2d_a: forward writes a as S(a) (lda = row stride of S, >= 8*c);  s2d_da: backward reads da
+   * from a gradient in S layout.  sd/sh/sw = plain extents of z per sample. */
+  int32_t s2d_a, s2d_da;
+  int32_t sd, sh, sw;
 } mi355_normact_desc;
 int mi355_normact_fwd(const mi355_normact_desc* d, void* stream);
 int mi355_normact_bwd_reduce(const mi355_normact_desc* d, void* stream);

@@ -1,0 +1,156 @@
+"""world_size-2 `gloo` tests of the data-parallel path on CPU: bucketed gradient all-reduce from
+grad-ready hooks (ddp.GradSync), parameter/buffer broadcast, the single stacked log reduce, and the
+whole GAN step (harness + sync) against a single-process run on the concatenated batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker_sync(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    from unet_bssfp_amd import ddp
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)                      # different init per rank on purpose
+        net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.BatchNorm1d(16), torch.nn.Linear(16, 4),
+                                  torch.nn.Linear(4, 4))   # last layer stays unused -> never fires
+        ddp.broadcast_module_state(net, 0)
+        w0 = net[0].weight.detach().clone()
+        gathered = [torch.zeros_like(w0) for _ in range(world)]
+        dist.all_gather(gathered, w0)
+        assert all(torch.equal(g, gathered[0]) for g in gathered), "broadcast did not equalise parameters"
+        sync = ddp.GradSync(list(net.parameters()), bucket_mb=0.0005)      # tiny buckets -> several of them
+        assert len(sync.buckets) >= 3
+        g = torch.Generator().manual_seed(7)
+        xs = torch.rand(world, 6, 8, generator=g)
+        out = net[2](net[1](net[0](xs[rank])))
+        out.pow(2).sum().backward()
+        sync.finish()
+        local = [None if p.grad is None else p.grad.detach().clone() for p in net.parameters()]
+        # reference: average of the per-rank gradients, computed by brute force
+        for p, mine in zip(net.parameters(), local):
+            if mine is None:
+                continue
+            assert p.grad.shape == p.shape
+        net.zero_grad()
+        ref = []
+        for r in range(world):
+            net.zero_grad()
+            o = net[2](net[1](net[0](xs[r])))
+            o.pow(2).sum().backward()
+            ref.append([None if p.grad is None else p.grad.detach().clone() for p in net.parameters()])
+        for i, mine in enumerate(local):
+            if mine is None:
+                assert ref[0][i] is None
+                continue
+            avg = sum(ref[r][i] for r in range(world)) / world
+            torch.testing.assert_close(mine, avg, rtol=1e-5, atol=1e-7)
+        logs = ddp.reduce_logs(torch.tensor([float(rank), 2.0]))
+        torch.testing.assert_close(logs, torch.tensor([(world - 1) / 2.0, 2.0]))
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, f"FAIL: {e!r}"))
+    finally:
+        dist.destroy_process_group()
+
+
+def _worker_gan(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    from oracle import unet_ref as R
+    from unet_bssfp_amd import ddp
+    from unet_bssfp_amd.gan import bSSFPToDWITensorModel, synthetic_batch
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        torch.manual_seed(rank)                            # ranks start different; attach() broadcasts rank 0
+        gen = R.RefGenerator("bssfp", dropout=0.0).train()
+        discr = R.RefDiscriminator("bssfp").train()
+        model = bSSFPToDWITensorModel("bssfp", gen=gen, discr=discr, optimizer_class=torch.optim.SGD, lr=1e-3)
+        ddp.attach(model)
+        unused = {id(p) for p in gen.blocks["dwi-tensor"].parameters()} | {id(p) for p in discr.d1["t1w"].parameters()}
+        for sync in (model.grad_sync_gen, model.grad_sync_discr):
+            for b in sync.buckets:
+                assert not any(id(p) in unused for p in b.params), "unused modality head must be excluded statically"
+        batch = synthetic_batch(2, 32, seed=50 + rank)
+        model.training_step(batch, 0)
+        logs = ddp.reduce_logs(model.stacked_logs())
+        digest = torch.stack([p.detach().double().sum() for p in model.parameters()])
+        gathered = [torch.zeros_like(digest) for _ in range(world)]
+        dist.all_gather(gathered, digest)
+        assert all(torch.allclose(g, gathered[0], rtol=0, atol=0) for g in gathered), "ranks diverged after the step"
+        q.put((rank, "ok", logs.tolist(), digest.tolist()))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, f"FAIL: {e!r} {traceback.format_exc()}", None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(worker, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    return sorted(res)
+
+
+def test_gradsync_buckets_average_and_broadcast_gloo():
+    res = _run(_worker_sync)
+    assert all(r[1] == "ok" for r in res), res
+
+
+def test_gan_step_data_parallel_matches_single_process_gloo():
+    """2 ranks x (N=2 per rank), SGD so that the update is linear in the averaged gradient.  The
+    generator (InstanceNorm: per-sample statistics) must equal the single-process step whose loss is
+    the mean of the two per-rank losses; ranks must stay bit-identical to each other."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from oracle import unet_ref as R
+    res = _run(_worker_gan)
+    assert all(r[1] == "ok" for r in res), [r[1] for r in res]
+    assert res[0][3] == res[1][3]
+    # single-process emulation: same init (rank 0's), per-rank batches, averaged gradients, per-rank BN
+    torch.manual_seed(0)
+    gen = R.RefGenerator("bssfp", dropout=0.0).train()
+    discr = R.RefDiscriminator("bssfp").train()
+    for p in discr.parameters():
+        p.requires_grad_(False)
+    grads = None
+    adv_l1 = []
+    import copy
+    for r in range(2):
+        d_r = copy.deepcopy(discr)                        # BatchNorm buffers are per rank
+        x, y = R.synthetic_batch(2, 32, seed=50 + r)
+        y_hat = gen(x)
+        logits = d_r(x, y_hat)
+        adv = torch.nn.functional.binary_cross_entropy_with_logits(logits, torch.ones_like(logits))
+        l1 = torch.nn.functional.l1_loss(y_hat, y)
+        adv_l1.append((adv.item(), l1.item()))
+        gen.zero_grad()
+        (adv + l1 * 100.0).backward()
+        g = [None if p.grad is None else p.grad.clone() for p in gen.parameters()]
+        grads = g if grads is None else [None if a is None else a + b for a, b in zip(grads, g)]
+    logs = res[0][2]
+    assert logs[0] == pytest.approx(sum(a for a, _ in adv_l1) / 2, rel=1e-5)          # gen_loss_adversarial
+    assert logs[1] == pytest.approx(sum(b for _, b in adv_l1) / 2, rel=1e-5)          # gen_loss_recon_L1

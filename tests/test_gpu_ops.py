@@ -301,3 +301,84 @@ def test_cpu_tensor_is_rejected_loudly(hip):
     gen = Generator("bssfp")
     with pytest.raises(_lib.Mi355Error):
         gen(torch.rand(1, 24, 32, 32, 32))
+
+
+# ------------------------------------------------------------------ space-to-depth PatchGAN path
+def to_s2d(x, dtype, cp):
+    """NCDHW f32 CPU tensor -> S(x) on the GPU (channels padded to cp per block)."""
+    ops = _ops()
+    n, c, d, h, w = x.shape
+    out = torch.zeros(ops.s2d_shape(n, d, h, w, cp), dtype=dtype, device=DEV)
+    ops.pack_ncdhw_s2d(x.to(DEV).float().contiguous(), out, cp, 0, cp)
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_s2d_layout_definition(hip, dtype):
+    g = torch.Generator().manual_seed(3)
+    x = q(torch.rand(2, 5, 4, 6, 8, generator=g), dtype)
+    s = to_s2d(x, dtype, 16).float().cpu()                       # (N, 3, 4, 5, 128)
+    xp = torch.nn.functional.pad(x, (1, 1, 1, 1, 1, 1))           # x[-1 .. D]
+    for blk in range(8):
+        bd, bh, bw = blk >> 2, (blk >> 1) & 1, blk & 1
+        ref = xp[:, :, bd::2, bh::2, bw::2][:, :, :3, :4, :5].permute(0, 2, 3, 4, 1)   # a[2j+b-1]
+        assert torch.equal(s[..., blk * 16: blk * 16 + 5], ref), blk
+        assert float(s[..., blk * 16 + 5: (blk + 1) * 16].abs().max()) == 0.0
+    back = _ops().unpack_ncdhw_s2d(s.to(DEV).to(dtype), 5, (4, 6, 8), 16, 0).cpu()
+    assert torch.equal(back, x)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,cin,cout,sp", [(1, 30, 32, (8, 8, 32)), (2, 32, 64, (8, 8, 8)), (1, 64, 128, (4, 4, 4))])
+def test_k4s2_conv_as_dense_k2_on_s2d(hip, dtype, n, cin, cout, sp):
+    from unet_bssfp_amd import functional as Fn
+    g = torch.Generator().manual_seed(17)
+    layer = _conv_layer((cin,), cout, 4, 2, 1, 4)
+    with torch.no_grad():
+        layer.weight.copy_(q(layer.weight, dtype))
+    x = q(torch.rand(n, cin, *sp, generator=g) - 0.3, dtype)
+    w_cpu = layer.weight.detach().clone().requires_grad_(True)
+    b_cpu = layer.bias.detach().clone().requires_grad_(True)
+    x_cpu = x.clone().requires_grad_(True)
+    z_ref = F.conv3d(x_cpu, w_cpu, b_cpu, 2, 1)
+    gz = q(torch.rand(z_ref.shape, generator=g) - 0.5, dtype)
+    z_ref.backward(gz)
+    layer = layer.to(DEV)
+    cp = _ops().round_up(cin, 16)
+    s = to_s2d(x, dtype, cp).requires_grad_(True)
+    z, part = Fn.ConvFn.apply(s, None, layer.weight, layer.bias, layer.spec, True, False, cp)
+    tol = TOL[dtype]
+    torch.testing.assert_close(from_act(z, cout), z_ref.detach(), **tol)
+    zc = z_ref.detach() - b_cpu.detach().view(1, -1, 1, 1, 1)
+    torch.testing.assert_close(part.sum(0).cpu()[0, :cout], zc.sum((0, 2, 3, 4)), rtol=2e-3, atol=2e-2 if dtype == torch.float32 else 0.5)
+    z.backward(to_act(gz, dtype))
+    dx = _ops().unpack_ncdhw_s2d(s.grad, cin, sp, cp, 0).cpu()
+    btol = tol if dtype == torch.float32 else dict(rtol=5e-2, atol=1e-1)
+    torch.testing.assert_close(dx, x_cpu.grad, **btol)
+    wscale = float(w_cpu.grad.abs().max())
+    torch.testing.assert_close(layer.weight.grad.cpu(), w_cpu.grad, rtol=tol["rtol"] * 5, atol=tol["atol"] * 5 * max(1.0, wscale))
+    torch.testing.assert_close(layer.bias.grad.cpu(), b_cpu.grad, rtol=tol["rtol"] * 5, atol=tol["atol"] * 50)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_normact_writes_and_reads_s2d(hip, dtype):
+    from unet_bssfp_amd import functional as Fn
+    g = torch.Generator().manual_seed(23)
+    n, c, sp = 2, 32, (4, 8, 8)
+    z = q(torch.randn(n, c, *sp, generator=g), dtype)
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.rand(c, generator=g) - 0.5
+    cfg = Fn.NormCfg("batch", c, slope=0.2)
+    zd1 = to_act(z, dtype).requires_grad_(True)
+    zd2 = to_act(z, dtype).requires_grad_(True)
+    mk = lambda: (torch.zeros(c, device=DEV), torch.ones(c, device=DEV))
+    rm1, rv1 = mk()
+    rm2, rv2 = mk()
+    a_plain = Fn.NormActFn.apply(zd1, None, gamma.to(DEV), beta.to(DEV), None, cfg, True, rm1, rv1, False)
+    a_s2d = Fn.NormActFn.apply(zd2, None, gamma.to(DEV), beta.to(DEV), None, cfg, True, rm2, rv2, True)
+    assert a_s2d.shape == (n, 3, 5, 5, 8 * c)
+    ref = to_s2d(from_act(a_plain, c), dtype, c)
+    assert torch.equal(a_s2d.float().cpu(), ref.float().cpu())
+    ga = q(torch.rand(n, c, *sp, generator=g) - 0.5, dtype)
+    a_plain.backward(to_act(ga, dtype))
+    a_s2d.backward(to_s2d(ga, dtype, c))
+    assert torch.equal(zd1.grad.float().cpu(), zd2.grad.float().cpu())

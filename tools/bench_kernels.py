@@ -1,0 +1,99 @@
+"""Micro-benchmarks of single kernels through the C ABI (HIP-event timing on the launch stream).
+Usage: python tools/bench_kernels.py [conv|wgrad|norm|all] [--dtype bf16|f32] [--reps 20]"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from unet_bssfp_amd import functional as Fn, ops
+from unet_bssfp_amd.nn import Conv3d
+
+DEV = "cuda:0"
+
+
+def timeit(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def bench_conv(dtype, reps, only=None):
+    cases = [("32->32 @128^3", 32, 0, 32, 128), ("24(32)->32 @128^3", 32, 0, 32, 128), ("96->32 @128^3 (32|64)", 32, 64, 32, 128),
+             ("64->64 @64^3", 64, 0, 64, 64), ("128->64 @64^3 (64|64)", 64, 64, 64, 64), ("128->128 @32^3", 128, 0, 128, 32),
+             ("256->256 @16^3", 256, 0, 256, 16), ("512->512 @8^3", 512, 0, 512, 8)]
+    for name, c0, c1, cout, s in cases:
+        if only and only not in name:
+            continue
+        layer = Conv3d(c0 + c1, cout, 3, 1, 1).to(DEV)
+        x0 = torch.randn(1, s, s, s, c0, device=DEV).to(dtype)
+        x1 = torch.randn(1, s, s, s, c1, device=DEV).to(dtype) if c1 else None
+        wp, coutp, _ = layer.spec.w_fwd(layer.weight, dtype, c0 + c1)
+        out = ops.new_act(1, s, s, s, cout, dtype, DEV)
+        bias = layer.bias.detach()
+        tiles, _ = ops.conv_num_tiles(x0, x1, wp, coutp, 3, 1, (1, 1, 1), out, (s, s, s))
+        part = torch.empty((tiles, 2, coutp), dtype=torch.float32, device=DEV)
+        ms = timeit(lambda: ops.conv_fwd(x0, x1, wp, coutp, bias, 3, 1, (1, 1, 1), out, (s, s, s), stats=part), reps)
+        fl = 2.0 * (c0 + c1) * cout * 27 * s ** 3
+        print(f"conv fwd  {name:28s} {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TFLOP/s")
+
+
+def bench_wgrad(dtype, reps, only=None):
+    cases = [("32->32 @128^3", 32, 32, 128), ("96->32 @128^3", 96, 32, 128), ("64->64 @64^3", 64, 64, 64),
+             ("128->128 @32^3", 128, 128, 32), ("256->256 @16^3", 256, 256, 16), ("512->512 @8^3", 512, 512, 8)]
+    for name, cin, cout, s in cases:
+        if only and only not in name:
+            continue
+        x = torch.randn(1, s, s, s, cin, device=DEV).to(dtype)
+        g = torch.randn(1, s, s, s, cout, device=DEV).to(dtype)
+        dw = torch.empty(cout, cin, 3, 3, 3, device=DEV)
+        ms = timeit(lambda: ops.conv_wgrad(x, None, g, (s, s, s), 1, (0, 0, 0), 3, 1, (1, 1, 1), dw, cout, cin,
+                                           cin * 27, 27, (9, 3, 1), (0, 0, 0), (1, 1, 1)), reps)
+        fl = 2.0 * cin * cout * 27 * s ** 3
+        print(f"wgrad     {name:28s} {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TFLOP/s")
+
+
+def bench_norm(dtype, reps, only=None):
+    es = 2 if dtype == torch.bfloat16 else 4
+    for name, c, s in [("C=32 @128^3", 32, 128), ("C=64 @64^3", 64, 64), ("C=128 @32^3", 128, 32)]:
+        if only and only not in name:
+            continue
+        z = torch.randn(1, s, s, s, c, device=DEV).to(dtype)
+        da = torch.randn(1, s, s, s, c, device=DEV).to(dtype)
+        gamma, beta = torch.ones(c, device=DEV), torch.zeros(c, device=DEV)
+        part, bpg = ops.channel_stats(z, 1)
+        mean, rstd = ops.norm_finalize(part, bpg, 1, c, s ** 3, None, 1e-5)
+        out = torch.empty_like(z)
+        nb = z.numel() * es
+        ms = timeit(lambda: ops.normact_fwd(z, 1, mean, rstd, gamma, beta, 0.1, 0.05, 1234, out=out), reps)
+        print(f"normact fwd (p=.05) {name:16s} {ms*1e3:9.1f} us  {2*nb/ms/1e6:8.1f} GB/s (2 passes)")
+        ms = timeit(lambda: ops.normact_fwd(z, 1, mean, rstd, gamma, beta, 0.1, 0.0, 0, out=out), reps)
+        print(f"normact fwd (p=0)   {name:16s} {ms*1e3:9.1f} us  {2*nb/ms/1e6:8.1f} GB/s (2 passes)")
+        ms = timeit(lambda: ops.channel_stats(z, 1), reps)
+        print(f"channel_stats       {name:16s} {ms*1e3:9.1f} us  {nb/ms/1e6:8.1f} GB/s (1 pass)")
+        ms = timeit(lambda: ops.normact_bwd(z, da, 1, mean, rstd, gamma, beta, 0.1, 0.05, 1234, True, True), reps)
+        print(f"normact bwd (all)   {name:16s} {ms*1e3:9.1f} us  {5*nb/ms/1e6:8.1f} GB/s (5 passes)")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="?", default="all")
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)
+    if a.what in ("conv", "all"):
+        bench_conv(dt, a.reps, a.only)
+    if a.what in ("wgrad", "all"):
+        bench_wgrad(dt, a.reps, a.only)
+    if a.what in ("norm", "all"):
+        bench_norm(dt, a.reps, a.only)

@@ -20,7 +20,7 @@ _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_v
 class WpackDesc(C.Structure):
     _fields_ = [("src", _vp), ("dst", _vp), ("cout", _i32), ("cin", _i32), ("coutp", _i32), ("cinp", _i32),
                 ("ks", _i32), ("s_co", _i64), ("s_ci", _i64), ("s_k", _i64 * 3),
-                ("tbase", _i32 * 3), ("tstep", _i32 * 3), ("dtype", _i32)]
+                ("tbase", _i32 * 3), ("tstep", _i32 * 3), ("dtype", _i32), ("s2d_mode", _i32), ("s2d_cp", _i32)]
 
 
 class ConvDesc(C.Structure):
@@ -40,7 +40,7 @@ class WgradDesc(C.Structure):
                 ("gs", _i32), ("goff", _i32 * 3), ("ks", _i32), ("stride", _i32), ("pad", _i32 * 3),
                 ("workspace", _vp), ("workspace_bytes", _i64),
                 ("dw", _vp), ("cout", _i32), ("cin", _i32), ("s_co", _i64), ("s_ci", _i64), ("s_k", _i64 * 3),
-                ("tbase", _i32 * 3), ("tstep", _i32 * 3), ("accumulate", _i32), ("dtype", _i32)]
+                ("tbase", _i32 * 3), ("tstep", _i32 * 3), ("accumulate", _i32), ("dtype", _i32), ("s2d_cp", _i32)]
 
 
 class NormActDesc(C.Structure):
@@ -49,7 +49,8 @@ class NormActDesc(C.Structure):
                 ("mean", _vp), ("rstd", _vp), ("gamma", _vp), ("beta", _vp),
                 ("slope", _f32), ("drop_p", _f32), ("seed", _u64), ("dtype", _i32),
                 ("da", _vp), ("ldda", _i32), ("dz", _vp), ("lddz", _i32),
-                ("part", _vp), ("blocks_per_group", _i32), ("sums", _vp), ("batch_stats", _i32)]
+                ("part", _vp), ("blocks_per_group", _i32), ("sums", _vp), ("batch_stats", _i32),
+                ("s2d_a", _i32), ("s2d_da", _i32), ("sd", _i32), ("sh", _i32), ("sw", _i32)]
 
 
 _SIGNATURES = {
@@ -57,6 +58,8 @@ _SIGNATURES = {
     "mi355_last_error": (C.c_char_p, []),
     "mi355_pack_ncdhw": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mi355_unpack_ncdhw": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _i32, _vp]),
+    "mi355_pack_ncdhw_s2d": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mi355_unpack_ncdhw_s2d": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mi355_weight_pack": (C.c_int, [C.POINTER(WpackDesc), _vp]),
     "mi355_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), _vp]),
     "mi355_conv_plan_id": (C.c_int, [C.POINTER(ConvDesc)]),

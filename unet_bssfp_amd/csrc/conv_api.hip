@@ -5,14 +5,16 @@ namespace {
 
 struct Plan {
   bool halo;
-  int shape;      // halo: 0 wide (2x4x32), 1 mid (2x8x16), 2 small (4x8x8)
+  int shape;      // halo tile: index into kTD/kTH/kTW/kVT
   int vt, ct;
   int tiles_d, tiles_h, tiles_w;
   long long tiles;
   int tiles_per_sample;
 };
 
-const int kTD[3] = {2, 2, 4}, kTH[3] = {4, 8, 8}, kTW[3] = {32, 16, 8};
+// 0 wide (2x4x32, 2 subtiles/wave)  1 mid (2x8x16, 2)  2 small (4x8x8, 2)
+// 3 wide4 (4x4x32, 4: bf16 thin-Cout layers)  4 mid1 (2x4x16, 1)  5 small1 (2x8x8, 1): more workgroups at the low levels
+const int kTD[6] = {2, 2, 4, 4, 2, 2}, kTH[6] = {4, 8, 8, 4, 4, 8}, kTW[6] = {32, 16, 8, 32, 16, 8}, kVT[6] = {2, 2, 2, 4, 1, 1};
 
 int make_plan(const mi355_conv_desc* d, Plan* p) {
   MI355_REQUIRE(d && d->x0 && d->wp && d->y, "conv: null pointer");
@@ -30,10 +32,22 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
                     (d->wo - 1) * d->os + d->ooff[2] < d->wy && d->ooff[0] >= 0 && d->ooff[1] >= 0 && d->ooff[2] >= 0,
                 "conv: output grid exceeds the output tensor");
   p->ct = (d->coutp % 64 == 0) ? 2 : 1;
-  p->halo = (d->ks == 3 && d->stride == 1);
+  p->halo = ((d->ks == 3 || d->ks == 2) && d->stride == 1);
   if (p->halo) {
     p->shape = d->wo > 16 ? 0 : (d->wo > 8 ? 1 : 2);
-    p->vt = 2;
+    auto count = [&](int sh, int ct) {
+      return (long long)ceil_div(d->do_, kTD[sh]) * ceil_div(d->ho, kTH[sh]) * ceil_div(d->wo, kTW[sh]) * d->n *
+             (d->coutp / (32 * ct));
+    };
+    if (p->shape == 0) {
+      // thin-Cout full-resolution layers in bf16: 4 voxel subtiles per weight fragment (halves L1 weight traffic)
+      if (false && d->dtype == MI355_DT_BF16 && p->ct == 1 && count(3, 1) >= 1024) p->shape = 3;  // measured slower (occupancy)
+    } else {
+      // low levels: few tiles -> favour more, smaller workgroups (the K loop is long, the grid is not)
+      if (count(p->shape, p->ct) < 512) p->ct = 1;
+      if (count(p->shape, p->ct) < 512) p->shape += 3;
+    }
+    p->vt = kVT[p->shape];
     p->tiles_d = ceil_div(d->do_, kTD[p->shape]);
     p->tiles_h = ceil_div(d->ho, kTH[p->shape]);
     p->tiles_w = ceil_div(d->wo, kTW[p->shape]);
@@ -72,15 +86,30 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
   a.m_total = (long long)d->n * d->do_ * d->ho * d->wo;
   dim3 grid((unsigned)p.tiles, (unsigned)(d->coutp / (32 * p.ct)));
   dim3 block(256);
-#define HALO(TD, TH, TW, CT)                                     \
-  do {                                                           \
-    constexpr int lds = conv_k3_halo_lds<T, TD, TH, TW>();       \
-    conv_k3_halo_kernel<T, TD, TH, TW, CT><<<grid, block, lds, st>>>(a); \
+#define HALO(KS, TD, TH, TW, CT)                                     \
+  do {                                                               \
+    constexpr int lds = conv_halo_lds<T, KS, TD, TH, TW>();          \
+    conv_halo_kernel<T, KS, TD, TH, TW, CT><<<grid, block, lds, st>>>(a); \
   } while (0)
+#define HALO_KS(KS)                                                  \
+    switch (p.shape * 10 + p.ct) {                                   \
+      case 1: HALO(KS, 2, 4, 32, 1); break;                          \
+      case 2: HALO(KS, 2, 4, 32, 2); break;                          \
+      case 11: HALO(KS, 2, 8, 16, 1); break;                         \
+      case 12: HALO(KS, 2, 8, 16, 2); break;                         \
+      case 21: HALO(KS, 4, 8, 8, 1); break;                          \
+      case 22: HALO(KS, 4, 8, 8, 2); break;                          \
+      case 41: HALO(KS, 2, 4, 16, 1); break;                         \
+      case 42: HALO(KS, 2, 4, 16, 2); break;                         \
+      case 51: HALO(KS, 2, 8, 8, 1); break;                          \
+      case 52: HALO(KS, 2, 8, 8, 2); break;                          \
+      default: mi355_set_error("conv: no kernel for plan %d/%d", p.shape, p.ct); return MI355_ERR_UNSUPPORTED; \
+    }
   if (p.halo) {
-    if (p.shape == 0) { if (p.ct == 2) HALO(2, 4, 32, 2); else HALO(2, 4, 32, 1); }
-    else if (p.shape == 1) { if (p.ct == 2) HALO(2, 8, 16, 2); else HALO(2, 8, 16, 1); }
-    else { if (p.ct == 2) HALO(4, 8, 8, 2); else HALO(4, 8, 8, 1); }
+    if (d->ks == 3) {
+      if (p.shape == 3) { if constexpr (sizeof(T) == 2) { HALO(3, 4, 4, 32, 1); } }
+      else { HALO_KS(3) }
+    } else { HALO_KS(2) }
   } else {
     if (p.vt == 2) {
       if (p.ct == 2) conv_gather_kernel<T, 2, 2><<<grid, block, 0, st>>>(a);
@@ -91,6 +120,7 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
     }
   }
 #undef HALO
+#undef HALO_KS
   return mi355_check_launch("conv_fwd");
 }
 

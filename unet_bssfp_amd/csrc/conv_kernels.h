@@ -5,24 +5,27 @@
 // each lane ends up with ONE output channel and 16 voxels: channel statistics are lane-local
 // sums and every store instruction writes two full 128-B (f32) channel rows.
 //
-//  conv_k3_halo_kernel : 3x3x3 stride-1 (U-Net convs and their data gradients, ~88 % of the FLOPs).
-//      The workgroup stages the (TD+2)x(TH+2)x(TW+2) halo of a 16-channel chunk in LDS once and
-//      re-reads it 27 times (LDS 256 B/clk/CU instead of L1 64 B/clk/CU); the next chunk's halo
+//  conv_halo_kernel    : KS^3 stride-1, KS = 3 (U-Net convs and their data gradients) or KS = 2
+//      (PatchGAN k4s2 convs re-expressed as dense k2s1 convs on space-to-depth tensors, and the
+//      data gradient of the k2s2 transposed convolution's forward).
+//      The workgroup stages the (TD+KS-1)x(TH+KS-1)x(TW+KS-1) halo of a 16-channel chunk in LDS once and
+//      re-reads it KS^3 times (LDS 256 B/clk/CU instead of L1 64 B/clk/CU); the next chunk's halo
 //      is prefetched into registers while the MFMAs run.
 //  conv_gather_kernel  : any cubic kernel / stride / padding (PatchGAN k4s2, transposed-conv
 //      parity classes, 1x1x1): A fragments are gathered straight from global memory.
 #pragma once
 #include "conv_common.h"
 
-template <typename T, int TD, int TH, int TW, int CT>
-__global__ __launch_bounds__(256) void conv_k3_halo_kernel(const ConvArgs a) {
+template <typename T, int KS, int TD, int TH, int TW, int CT>
+__global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a) {
   constexpr int ES = sizeof(T);
   constexpr int RS = 32 / TW;                 // rows (h) per 32-voxel subtile
   constexpr int SPD = TH / RS;                // subtiles per d-slice
   constexpr int NSUB = TD * SPD;
   constexpr int VT = NSUB / 4;
   static_assert(NSUB % 4 == 0 && TW * RS == 32 && TH % RS == 0, "tile shape");
-  constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
+  constexpr int NTAP = KS * KS * KS;
+  constexpr int HD = TD + KS - 1, HH = TH + KS - 1, HW = TW + KS - 1;
   constexpr int VS = 16 * ES + 16;            // LDS bytes per halo voxel (+16: bank spread)
   constexpr int PPV = ES;                     // 16-B pieces per voxel (16 ch * ES / 16)
   constexpr int NPIECE = HD * HH * HW * PPV;
@@ -100,26 +103,31 @@ __global__ __launch_bounds__(256) void conv_k3_halo_kernel(const ConvArgs a) {
     store_chunk();
     __syncthreads();
     if (c + 1 < a.nchunks) load_chunk(c + 1);   // in flight under the MFMAs
-    const char* wc = wlane + (long long)c * 27 * wtap;
+    const char* wc = wlane + (long long)c * NTAP * wtap;
+    // weight fragments are fetched PG taps at a time (all loads of a group in flight together,
+    // one L2 latency per group instead of one per tap); bf16: a whole kd-plane, f32: one kw-row
+    constexpr int PG = (ES == 2) ? (KS == 3 ? 9 : NTAP) : KS;
 #pragma unroll
-    for (int kd = 0; kd < 3; ++kd)
+    for (int g0 = 0; g0 < NTAP; g0 += PG) {
+      Frag<T> b[PG][CT];
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
+      for (int t = 0; t < PG; ++t)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int tap = (kd * 3 + kh) * 3 + kw;
-          const int toff = ((kd * HH + kh) * HW + kw) * VS;
-          Frag<T> b[CT];
+        for (int ct = 0; ct < CT; ++ct) b[t][ct].load(wc + (g0 + t) * wtap + ct * (32 * 16 * ES));
 #pragma unroll
-          for (int ct = 0; ct < CT; ++ct) b[ct].load(wc + tap * wtap + ct * (32 * 16 * ES));
+      for (int t = 0; t < PG; ++t) {
+        const int tap = g0 + t;
+        const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
+        const int toff = ((kd * HH + kh) * HW + kw) * VS;
 #pragma unroll
-          for (int vt = 0; vt < VT; ++vt) {
-            Frag<T> af;
-            af.load(smem + lbase[vt] + toff);
+        for (int vt = 0; vt < VT; ++vt) {
+          Frag<T> af;
+          af.load(smem + lbase[vt] + toff);
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) mma16(af, b[ct], acc[vt][ct]);
-          }
+          for (int ct = 0; ct < CT; ++ct) mma16(af, b[t][ct], acc[vt][ct]);
         }
+      }
+    }
   }
 
   // ---- epilogue ----
@@ -136,10 +144,10 @@ __global__ __launch_bounds__(256) void conv_k3_halo_kernel(const ConvArgs a) {
   conv_epilogue<T, VT, CT>(a, acc, yoff, co_base, blockIdx.x, reinterpret_cast<float*>(smem));
 }
 
-template <typename T, int TD, int TH, int TW>
-constexpr int conv_k3_halo_lds() {
+template <typename T, int KS, int TD, int TH, int TW>
+constexpr int conv_halo_lds() {
   // staging halo, or the 4*CT*64 floats of the statistics reduction (always smaller)
-  return (TD + 2) * (TH + 2) * (TW + 2) * (16 * (int)sizeof(T) + 16);
+  return (TD + KS - 1) * (TH + KS - 1) * (TW + KS - 1) * (16 * (int)sizeof(T) + 16);
 }
 
 // ------------------------------------------------------------------------------------------

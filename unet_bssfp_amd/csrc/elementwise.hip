@@ -7,16 +7,29 @@ namespace {
 
 constexpr int kRowsPerStatBlock = 2048;
 
+// ------------------------------------------------------------------ space-to-depth addressing
+// S(a)[n, jd, jh, jw, blk*C + c] = a[n, 2jd+bd-1, 2jh+bh-1, 2jw+bw-1, c], blk = bd*4 + bh*2 + bw, extents
+// (D/2+1, H/2+1, W/2+1): a k4 s2 p1 convolution of `a` is a dense k2 s1 p0 convolution of S(a).
+struct S2D { int d, h, w, cblk; };   // extents of the plain tensor (per sample); d == 0: off
+__device__ __forceinline__ long long s2d_offset(const S2D& q, long long row /* n*D*H*W + ... */, int ld) {
+  const int w = (int)(row % q.w); long long t = row / q.w;
+  const int h = (int)(t % q.h); t /= q.h;
+  const int d = (int)(t % q.d); const long long n = t / q.d;
+  const long long srow = ((n * (q.d / 2 + 1) + ((d + 1) >> 1)) * (q.h / 2 + 1) + ((h + 1) >> 1)) * (q.w / 2 + 1) + ((w + 1) >> 1);
+  const int blk = ((d + 1) & 1) * 4 + ((h + 1) & 1) * 2 + ((w + 1) & 1);
+  return srow * ld + (long long)blk * q.cblk;
+}
+
 // ------------------------------------------------------------------ pack / unpack
 template <typename T>
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src, T* __restrict__ dst, int c,
-                                                    long long v, int ld, int coff, int zero_to) {
+                                                    long long v, int ld, int coff, int zero_to, S2D q) {
   constexpr int EPV = Elem<T>::kPer16B;
   const long long vox = (long long)blockIdx.x * 256 + threadIdx.x;
   const int n = blockIdx.y;
   if (vox >= v) return;
   const float* s = src + (long long)n * c * v + vox;
-  T* drow = dst + ((long long)n * v + vox) * ld;
+  T* drow = q.d ? dst + s2d_offset(q, (long long)n * v + vox, ld) : dst + ((long long)n * v + vox) * ld;
   for (int e0 = coff; e0 < zero_to; e0 += EPV) {
     Vec16<T> o;
 #pragma unroll
@@ -30,11 +43,11 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src
 
 template <typename T>
 __global__ __launch_bounds__(256) void unpack_kernel(const T* __restrict__ src, float* __restrict__ dst, int c,
-                                                      long long v, int ld, int coff) {
+                                                      long long v, int ld, int coff, S2D q) {
   const long long vox = (long long)blockIdx.x * 256 + threadIdx.x;
   const int n = blockIdx.y;
   if (vox >= v) return;
-  const T* srow = src + ((long long)n * v + vox) * ld + coff;
+  const T* srow = (q.d ? src + s2d_offset(q, (long long)n * v + vox, ld) : src + ((long long)n * v + vox) * ld) + coff;
   float* d = dst + (long long)n * c * v + vox;
   for (int ch = 0; ch < c; ++ch) d[(long long)ch * v] = Elem<T>::load(srow + ch);
 }
@@ -45,6 +58,7 @@ struct WpackArgs {
   int cout, cin, coutp, cinp, ks;
   long long s_co, s_ci, s_k0, s_k1, s_k2;
   int tb0, tb1, tb2, ts0, ts1, ts2;
+  int s2d_mode, s2d_cp;   // 1: the GEMM cin index is (block, channel) of a space-to-depth tensor; 2: the cout index is
 };
 template <typename T>
 __global__ __launch_bounds__(256) void wpack_kernel(const WpackArgs a) {
@@ -56,12 +70,15 @@ __global__ __launch_bounds__(256) void wpack_kernel(const WpackArgs a) {
   const int co = (int)((idx / 16) % a.coutp);
   const int tap = (int)((idx / (16ll * a.coutp)) % ntaps);
   const int chunk = (int)(idx / (16ll * a.coutp * ntaps));
-  const int ci = chunk * 16 + e;
+  int ci = chunk * 16 + e;
+  int cor = co, blk = 0;
+  if (a.s2d_mode == 1) { blk = ci / a.s2d_cp; ci = ci % a.s2d_cp; }
+  if (a.s2d_mode == 2) { blk = cor / a.s2d_cp; cor = cor % a.s2d_cp; }
   float v = 0.f;
-  if (co < a.cout && ci < a.cin) {
+  if (cor < a.cout && ci < a.cin && blk < 8) {
     const int td = tap / (a.ks * a.ks), th = (tap / a.ks) % a.ks, tw = tap % a.ks;
-    v = a.src[co * a.s_co + ci * a.s_ci + (a.tb0 + a.ts0 * td) * a.s_k0 + (a.tb1 + a.ts1 * th) * a.s_k1 +
-              (a.tb2 + a.ts2 * tw) * a.s_k2];
+    v = a.src[cor * a.s_co + ci * a.s_ci + (a.tb0 + a.ts0 * td + (blk >> 2)) * a.s_k0 +
+              (a.tb1 + a.ts1 * th + ((blk >> 1) & 1)) * a.s_k1 + (a.tb2 + a.ts2 * tw + (blk & 1)) * a.s_k2];
   }
   Elem<T>::store(reinterpret_cast<T*>(a.dst) + idx, v);
 }
@@ -212,6 +229,8 @@ struct NormActArgs {
   float slope; float drop_scale; unsigned thr16; unsigned long long seed;
   const char* da; int ldda; char* dz; int lddz;
   float* part; int blocks_per_group; const float* sums; int batch_stats;
+  S2D s2d_a;      // forward: write `a` in space-to-depth layout
+  S2D s2d_da;     // backward: read `da` from a space-to-depth tensor
 };
 
 template <typename T>
@@ -246,7 +265,8 @@ __global__ __launch_bounds__(256) void normact_fwd_kernel(const NormActArgs q) {
       if (q.thr16) t = drop_keep(q.seed, e0 + j, q.thr16) ? t * q.drop_scale : 0.f;
       v.f[j] = t > 0.f ? t : t * q.slope;
     }
-    v.store(ab + row * q.lda + ch0);
+    if (q.s2d_a.d) v.store(reinterpret_cast<T*>(q.a) + s2d_offset(q.s2d_a, (long long)g * q.rows_per_group + row, q.lda) + ch0);
+    else v.store(ab + row * q.lda + ch0);
   }
 }
 
@@ -294,7 +314,8 @@ __global__ __launch_bounds__(256) void normact_bwd_reduce_kernel(const NormActAr
       [&](long long row, int ch0, float* s0, float* s1) {
         Vec16<T> zv, dv;
         zv.load(zb + row * q.ldz + ch0);
-        dv.load(db + row * q.ldda + ch0);
+        if (q.s2d_da.d) dv.load(reinterpret_cast<const T*>(q.da) + s2d_offset(q.s2d_da, (long long)g * q.rows_per_group + row, q.ldda) + ch0);
+        else dv.load(db + row * q.ldda + ch0);
         const unsigned long long e0 = ((unsigned long long)g * q.rows_per_group + row) * q.c + ch0;
 #pragma unroll
         for (int j = 0; j < EPV; ++j) {
@@ -357,7 +378,8 @@ __global__ __launch_bounds__(256) void normact_bwd_apply_kernel(const NormActArg
   for (long long row = (long long)blockIdx.x * rpp + rsub; row < q.rows_per_group; row += stride) {
     Vec16<T> zv, dv;
     zv.load(zb + row * q.ldz + ch0);
-    dv.load(db + row * q.ldda + ch0);
+    if (q.s2d_da.d) dv.load(reinterpret_cast<const T*>(q.da) + s2d_offset(q.s2d_da, (long long)g * q.rows_per_group + row, q.ldda) + ch0);
+    else dv.load(db + row * q.ldda + ch0);
     const unsigned long long e0 = ((unsigned long long)g * q.rows_per_group + row) * q.c + ch0;
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
@@ -552,8 +574,8 @@ int check_rows(int c, int ld, int dtype, const char* who) {
 
 extern "C" {
 
-int mi355_pack_ncdhw(const float* src, void* dst, int32_t n, int32_t c, int64_t v, int32_t ld, int32_t coff,
-                     int32_t zero_to, int32_t dtype, void* stream) {
+static int pack_impl(const float* src, void* dst, int32_t n, int32_t c, int64_t v, int32_t ld, int32_t coff,
+                     int32_t zero_to, int32_t dtype, S2D q, void* stream) {
   MI355_REQUIRE(src && dst && n > 0 && c > 0 && v > 0, "pack: bad argument");
   const int epv = dtype == MI355_DT_F32 ? 4 : 8;
   MI355_REQUIRE(dtype == MI355_DT_F32 || dtype == MI355_DT_BF16, "pack: bad dtype");
@@ -561,34 +583,69 @@ int mi355_pack_ncdhw(const float* src, void* dst, int32_t n, int32_t c, int64_t 
                 "pack: channel window [%d,%d) of ld %d must be 16-byte aligned and hold c=%d", coff, zero_to, ld, c);
   dim3 grid((unsigned)((v + 255) / 256), n);
   if (dtype == MI355_DT_F32)
-    hipLaunchKernelGGL(pack_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, c, (long long)v, ld, coff, zero_to);
+    hipLaunchKernelGGL(pack_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, c, (long long)v, ld, coff, zero_to, q);
   else
-    hipLaunchKernelGGL(pack_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, c, (long long)v, ld, coff, zero_to);
+    hipLaunchKernelGGL(pack_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, c, (long long)v, ld, coff, zero_to, q);
   return mi355_check_launch("pack");
 }
 
-int mi355_unpack_ncdhw(const void* src, float* dst, int32_t n, int32_t c, int64_t v, int32_t ld, int32_t coff,
-                       int32_t dtype, void* stream) {
+static int unpack_impl(const void* src, float* dst, int32_t n, int32_t c, int64_t v, int32_t ld, int32_t coff,
+                       int32_t dtype, S2D q, void* stream) {
   MI355_REQUIRE(src && dst && n > 0 && c > 0 && v > 0 && coff >= 0 && coff + c <= ld, "unpack: bad argument");
   MI355_REQUIRE(dtype == MI355_DT_F32 || dtype == MI355_DT_BF16, "unpack: bad dtype");
   dim3 grid((unsigned)((v + 255) / 256), n);
   if (dtype == MI355_DT_F32)
-    hipLaunchKernelGGL(unpack_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, dst, c, (long long)v, ld, coff);
+    hipLaunchKernelGGL(unpack_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, dst, c, (long long)v, ld, coff, q);
   else
-    hipLaunchKernelGGL(unpack_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, c, (long long)v, ld, coff);
+    hipLaunchKernelGGL(unpack_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, c, (long long)v, ld, coff, q);
   return mi355_check_launch("unpack");
+}
+
+int mi355_pack_ncdhw(const float* src, void* dst, int32_t n, int32_t c, int64_t v, int32_t ld, int32_t coff,
+                     int32_t zero_to, int32_t dtype, void* stream) {
+  return pack_impl(src, dst, n, c, v, ld, coff, zero_to, dtype, S2D{0, 0, 0, 0}, stream);
+}
+
+int mi355_unpack_ncdhw(const void* src, float* dst, int32_t n, int32_t c, int64_t v, int32_t ld, int32_t coff,
+                       int32_t dtype, void* stream) {
+  return unpack_impl(src, dst, n, c, v, ld, coff, dtype, S2D{0, 0, 0, 0}, stream);
+}
+
+static int check_s2d(int d, int h, int w, int cblk, int ld, const char* who) {
+  MI355_REQUIRE(d > 0 && h > 0 && w > 0 && d % 2 == 0 && h % 2 == 0 && w % 2 == 0, "%s: space-to-depth needs even extents", who);
+  MI355_REQUIRE(cblk > 0 && cblk % 16 == 0 && ld >= 8 * cblk, "%s: space-to-depth row must hold 8 channel blocks", who);
+  return MI355_OK;
+}
+
+int mi355_pack_ncdhw_s2d(const float* src, void* dst, int32_t n, int32_t c, int32_t d, int32_t h, int32_t w,
+                         int32_t cblk, int32_t ld, int32_t coff, int32_t zero_to, int32_t dtype, void* stream) {
+  int rc = check_s2d(d, h, w, cblk, ld, "pack_s2d");
+  if (rc) return rc;
+  MI355_REQUIRE(zero_to <= cblk, "pack_s2d: channel window exceeds the block");
+  return pack_impl(src, dst, n, c, (int64_t)d * h * w, ld, coff, zero_to, dtype, S2D{d, h, w, cblk}, stream);
+}
+
+int mi355_unpack_ncdhw_s2d(const void* src, float* dst, int32_t n, int32_t c, int32_t d, int32_t h, int32_t w,
+                           int32_t cblk, int32_t ld, int32_t coff, int32_t dtype, void* stream) {
+  int rc = check_s2d(d, h, w, cblk, ld, "unpack_s2d");
+  if (rc) return rc;
+  MI355_REQUIRE(coff + c <= cblk, "unpack_s2d: channel window exceeds the block");
+  return unpack_impl(src, dst, n, c, (int64_t)d * h * w, ld, coff, dtype, S2D{d, h, w, cblk}, stream);
 }
 
 int mi355_weight_pack(const mi355_wpack_desc* d, void* stream) {
   MI355_REQUIRE(d && d->src && d->dst, "weight_pack: null pointer");
   MI355_REQUIRE(d->coutp % 32 == 0 && d->cinp % 16 == 0 && d->cout <= d->coutp && d->cin <= d->cinp && d->ks >= 1 && d->ks <= 4,
                 "weight_pack: bad extents");
+  MI355_REQUIRE(d->s2d_mode >= 0 && d->s2d_mode <= 2 && (d->s2d_mode == 0 || (d->s2d_cp > 0 && d->s2d_cp % 16 == 0)),
+                "weight_pack: bad space-to-depth mode");
   MI355_REQUIRE(d->dtype == MI355_DT_F32 || d->dtype == MI355_DT_BF16, "weight_pack: bad dtype");
   WpackArgs a;
   a.src = d->src; a.dst = d->dst; a.cout = d->cout; a.cin = d->cin; a.coutp = d->coutp; a.cinp = d->cinp; a.ks = d->ks;
   a.s_co = d->s_co; a.s_ci = d->s_ci; a.s_k0 = d->s_k[0]; a.s_k1 = d->s_k[1]; a.s_k2 = d->s_k[2];
   a.tb0 = d->tbase[0]; a.tb1 = d->tbase[1]; a.tb2 = d->tbase[2];
   a.ts0 = d->tstep[0]; a.ts1 = d->tstep[1]; a.ts2 = d->tstep[2];
+  a.s2d_mode = d->s2d_mode; a.s2d_cp = d->s2d_cp;
   const long long total = (long long)d->cinp * d->ks * d->ks * d->ks * d->coutp;
   dim3 grid((unsigned)((total + 255) / 256));
   if (d->dtype == MI355_DT_F32) hipLaunchKernelGGL(wpack_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -648,6 +705,15 @@ static int fill_normact(const mi355_normact_desc* d, NormActArgs* q, const char*
   q->seed = d->seed;
   q->da = (const char*)d->da; q->ldda = d->ldda; q->dz = (char*)d->dz; q->lddz = d->lddz;
   q->part = d->part; q->blocks_per_group = d->blocks_per_group; q->sums = d->sums; q->batch_stats = d->batch_stats;
+  q->s2d_a = S2D{0, 0, 0, 0};
+  q->s2d_da = S2D{0, 0, 0, 0};
+  if (d->s2d_a || d->s2d_da) {
+    MI355_REQUIRE((long long)d->sd * d->sh * d->sw * (d->groups == 1 ? 1 : 1) > 0 &&
+                  ((long long)d->rows_per_group * d->groups) % ((long long)d->sd * d->sh * d->sw) == 0,
+                  "%s: space-to-depth extents do not match the row count", who);
+    if (d->s2d_a) { int rc2 = check_s2d(d->sd, d->sh, d->sw, d->c, d->lda, who); if (rc2) return rc2; q->s2d_a = S2D{d->sd, d->sh, d->sw, d->c}; }
+    if (d->s2d_da) { int rc2 = check_s2d(d->sd, d->sh, d->sw, d->c, d->ldda, who); if (rc2) return rc2; q->s2d_da = S2D{d->sd, d->sh, d->sw, d->c}; }
+  }
   return MI355_OK;
 }
 

@@ -108,6 +108,7 @@ struct WreduceArgs {
   long long s_co, s_ci, s_k0, s_k1, s_k2;
   int tb0, tb1, tb2, ts0, ts1, ts2;
   int accumulate;
+  int s2d_cp;
 };
 
 // 256 threads = 32 consecutive elements x 8 slab lanes; fixed-order LDS combine (deterministic)
@@ -132,12 +133,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WreduceArgs a) 
 #pragma unroll
   for (int q = 1; q < 8; ++q) s += red[q][e];
   const int co = (int)(idx % a.coutp);
-  const int ci = (int)((idx / a.coutp) % a.cinp);
+  int ci = (int)((idx / a.coutp) % a.cinp);
   const int tap = (int)(idx / ((long long)a.coutp * a.cinp));
-  if (co >= a.cout || ci >= a.cin) return;
+  int blk = 0;
+  if (a.s2d_cp) { blk = ci / a.s2d_cp; ci = ci % a.s2d_cp; }
+  if (co >= a.cout || ci >= a.cin || blk >= 8) return;
   const int td = tap / (a.ks * a.ks), th = (tap / a.ks) % a.ks, tw = tap % a.ks;
-  const long long dst = co * a.s_co + ci * a.s_ci + (a.tb0 + a.ts0 * td) * a.s_k0 +
-                        (a.tb1 + a.ts1 * th) * a.s_k1 + (a.tb2 + a.ts2 * tw) * a.s_k2;
+  const long long dst = co * a.s_co + ci * a.s_ci + (a.tb0 + a.ts0 * td + (blk >> 2)) * a.s_k0 +
+                        (a.tb1 + a.ts1 * th + ((blk >> 1) & 1)) * a.s_k1 + (a.tb2 + a.ts2 * tw + (blk & 1)) * a.s_k2;
   if (a.accumulate) a.dw[dst] += s; else a.dw[dst] = s;
 }
 
@@ -162,10 +165,12 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* p) {
   return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <int TD, int TH, int TW>
-__global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const WgradArgs a, int tiles_d, int tiles_h,
-                                                                int tiles_w, int ntiles) {
-  constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
+template <int KS, int TD, int TH, int TW>
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradArgs a, int tiles_d, int tiles_h,
+                                                             int tiles_w, int ntiles) {
+  constexpr int NT = KS * KS * KS;
+  constexpr int TPWV = (NT + 3) / 4;          // taps per wave
+  constexpr int HD = TD + KS - 1, HH = TH + KS - 1, HW = TW + KS - 1;
   constexpr int XROWS = HD * HH * HW, GROWS = TD * TH * TW;
   constexpr int NPX = (XROWS * 4 + 255) / 256, NPG = (GROWS * 4 + 255) / 256;
   constexpr int SEGS = TW / 16;
@@ -184,19 +189,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const WgradArgs a
   const int cx_lim = (first ? a.c0 : a.c1) - cix;      // channels of this source left from cix
   const int cg_lim = a.cg - co_base;
 
-  int toff[7];
+  int toff[TPWV];
 #pragma unroll
-  for (int i = 0; i < 7; ++i) {
+  for (int i = 0; i < TPWV; ++i) {
     const int tap = wave + 4 * i;
-    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-    toff[i] = tap < 27 ? ((kd * HH + kh) * HW + kw) * 64 : 0;
+    const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
+    toff[i] = tap < NT ? ((kd * HH + kh) * HW + kw) * 64 : 0;
   }
   const int gi = lane & 15;
   const int lane_off = (8 * h + (gi >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (gi & 3)) * 2;
 
-  f32x16 acc[7];
+  f32x16 acc[TPWV];
 #pragma unroll
-  for (int i = 0; i < 7; ++i)
+  for (int i = 0; i < TPWV; ++i)
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
@@ -243,18 +248,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const WgradArgs a
       const char* xp = xs + ((sd * HH + sh) * HW + seg * 16) * 64 + lane_off;
       const bf16x8 b = frag_tr(gp);
 #pragma unroll
-      for (int i = 0; i < 7; ++i) {
+      for (int i = 0; i < TPWV; ++i) {
         const bf16x8 af = frag_tr(xp + toff[i]);
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b, acc[i], 0, 0, 0);
       }
     }
   }
-  float* sl = a.slab + ((long long)blockIdx.x * 27) * a.cinp * a.coutp;
+  float* sl = a.slab + ((long long)blockIdx.x * NT) * a.cinp * a.coutp;
   const int co = co_base + r;
 #pragma unroll
-  for (int i = 0; i < 7; ++i) {
+  for (int i = 0; i < TPWV; ++i) {
     const int tap = wave + 4 * i;
-    if (tap < 27) {
+    if (tap < NT) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int row = ci_base + acc_row(j, h);
@@ -276,6 +281,8 @@ int wplan(const mi355_wgrad_desc* d, WPlan* p) {
   MI355_REQUIRE(d->c0 > 0 && d->c0 % 16 == 0 && d->c1 % 16 == 0 && d->cg % 16 == 0, "wgrad: channels must be multiples of 16");
   MI355_REQUIRE(d->c1 == 0 || (d->x1 && d->c0 % 32 == 0), "wgrad: concat split must be a multiple of 32");
   MI355_REQUIRE(d->cin <= d->c0 + d->c1 && d->cout <= d->cg, "wgrad: real extents exceed padded ones");
+  MI355_REQUIRE(d->s2d_cp == 0 || (d->s2d_cp % 16 == 0 && d->c1 == 0 && d->c0 == 8 * d->s2d_cp && d->cin <= d->s2d_cp),
+                "wgrad: bad space-to-depth operand");
   p->ks = d->ks;
   p->tpw = d->ks == 1 ? 1 : (d->ks == 3 ? 9 : 8);
   const int nt = d->ks * d->ks * d->ks;
@@ -296,7 +303,7 @@ int wplan(const mi355_wgrad_desc* d, WPlan* p) {
   p->splits = (int)s;
   p->nslabs = p->splits * 4;
   // fast path: bf16, 3x3x3 stride 1, g on the same grid as the outputs
-  p->fast = d->dtype == MI355_DT_BF16 && d->ks == 3 && d->stride == 1 && d->gs == 1 && d->goff[0] == 0 &&
+  p->fast = d->dtype == MI355_DT_BF16 && (d->ks == 3 || d->ks == 2) && d->stride == 1 && d->gs == 1 && d->goff[0] == 0 &&
             d->goff[1] == 0 && d->goff[2] == 0 && d->gd == d->do_ && d->gh == d->ho && d->gw == d->wo &&
             d->ld0 % 8 == 0 && (d->c1 == 0 || d->ld1 % 8 == 0) && d->ldg % 8 == 0;
   if (p->fast) {
@@ -357,13 +364,14 @@ extern "C" int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream) {
   a.splits = p.splits; a.tap_groups = p.tap_groups; a.rows = p.rows;
   if (p.fast) {
     dim3 grid(p.splits, p.ci_tiles, p.co_tiles), block(256);
-    if (p.shape == 0) {
-      constexpr int lds = (4 * 6 * 34 + 2 * 4 * 32) * 64;
-      wgrad_k3_bf16_kernel<2, 4, 32><<<grid, block, lds, st>>>(a, p.tiles_d, p.tiles_h, p.tiles_w, p.ntiles);
-    } else {
-      constexpr int lds = (4 * 10 * 18 + 2 * 8 * 16) * 64;
-      wgrad_k3_bf16_kernel<2, 8, 16><<<grid, block, lds, st>>>(a, p.tiles_d, p.tiles_h, p.tiles_w, p.ntiles);
-    }
+#define WG_FAST(KS, TD, TH, TW)                                                                   \
+  do {                                                                                            \
+    constexpr int lds = ((TD + KS - 1) * (TH + KS - 1) * (TW + KS - 1) + TD * TH * TW) * 64;      \
+    wgrad_bf16_kernel<KS, TD, TH, TW><<<grid, block, lds, st>>>(a, p.tiles_d, p.tiles_h, p.tiles_w, p.ntiles); \
+  } while (0)
+    if (d->ks == 3) { if (p.shape == 0) WG_FAST(3, 2, 4, 32); else WG_FAST(3, 2, 8, 16); }
+    else { if (p.shape == 0) WG_FAST(2, 2, 4, 32); else WG_FAST(2, 2, 8, 16); }
+#undef WG_FAST
   } else if (d->dtype == MI355_DT_F32) launch_wgrad<float>(a, p, st);
   else launch_wgrad<bf16_t>(a, p, st);
   rc = mi355_check_launch("conv_wgrad");
@@ -376,6 +384,7 @@ extern "C" int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream) {
   q.tb0 = d->tbase[0]; q.tb1 = d->tbase[1]; q.tb2 = d->tbase[2];
   q.ts0 = d->tstep[0]; q.ts1 = d->tstep[1]; q.ts2 = d->tstep[2];
   q.accumulate = d->accumulate;
+  q.s2d_cp = d->s2d_cp;
   const long long per = (long long)q.ntaps * q.cinp * q.coutp;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 31) / 32)), dim3(256), 0, st, q);
   return mi355_check_launch("wgrad_reduce");

@@ -61,20 +61,30 @@ class PackFn(Function):
 
     @staticmethod
     def forward(ctx, cp, dtype, *srcs):
+        s2d = cp < 0                     # cp < 0: write the space-to-depth tensor S(.) with |cp| channels per block
+        cp = abs(cp)
+        ctx.s2d = s2d
         n, _, d, h, w = srcs[0].shape
+        ctx.dims = (d, h, w)
         epv = 4 if dtype == torch.float32 else 8
         ctx.split = None
         if len(srcs) > 1 and any(s.shape[1] % epv for s in srcs[:-1]):
             # channel boundaries that are not 16-byte aligned: concatenate first (boundary plumbing)
             ctx.split = [s.shape[1] for s in srcs]
             srcs = (torch.cat([s.detach().to(torch.float32) for s in srcs], dim=1),)
-        out = ops.new_act(n, d, h, w, cp, dtype, srcs[0].device)
+        if s2d:
+            out = torch.zeros(ops.s2d_shape(n, d, h, w, cp), dtype=dtype, device=srcs[0].device)
+        else:
+            out = ops.new_act(n, d, h, w, cp, dtype, srcs[0].device)
         offs, off = [], 0
         for i, s in enumerate(srcs):
             c = s.shape[1]
             last = i == len(srcs) - 1
             s32 = s.detach().to(torch.float32).contiguous()
-            ops.pack_ncdhw(s32, out, off, cp if last else off + c)
+            if s2d:
+                ops.pack_ncdhw_s2d(s32, out, cp, off, cp if last else off + c)
+            else:
+                ops.pack_ncdhw(s32, out, off, cp if last else off + c)
             offs.append((off, c))
             off += c
         ctx.offs = offs
@@ -85,6 +95,15 @@ class PackFn(Function):
     def backward(ctx, g):
         g = ops.as_act(g)
         grads = []
+        if ctx.s2d:
+            cp = g.shape[4] // 8
+            if ctx.split is not None:
+                full = ops.unpack_ncdhw_s2d(g, sum(ctx.split), ctx.dims, cp, 0)
+                pieces = torch.split(full, ctx.split, dim=1)
+                return (None, None, *[pc.contiguous() if ctx.needs_input_grad[2 + i] else None for i, pc in enumerate(pieces)])
+            for i, (off, c) in enumerate(ctx.offs):
+                grads.append(ops.unpack_ncdhw_s2d(g, c, ctx.dims, cp, off) if ctx.needs_input_grad[2 + i] else None)
+            return (None, None, *grads)
         if ctx.split is not None:
             full = ops.unpack_ncdhw(g, sum(ctx.split), 0)
             pieces = torch.split(full, ctx.split, dim=1)
@@ -151,6 +170,20 @@ class ConvSpec:
         return self.cache.get(("ddgrad", dtype, cinp), w, lambda: ops.weight_pack(
             w.detach(), self.cin, self.cout, 2, self.cout * 8, 8, (4, 2, 1), (0, 0, 0), (1, 1, 1), dtype, cinp))
 
+    # k4 s2 p1 on a space-to-depth input (dense k2 s1): W'[j][co][blk*cp + c] = w[co][c][2j + b]
+    def w_fwd_s2d(self, w, dtype, cp):
+        k = self.ks
+        return self.cache.get(("fwd_s2d", dtype, cp), w, lambda: ops.weight_pack(
+            w.detach(), self.cout, self.cin, 2, self.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (2, 2, 2),
+            dtype, cinp=8 * cp, s2d_mode=1, s2d_cp=cp))
+
+    def w_dgrad_s2d(self, w, dtype, cinp, cp):
+        # dS[i][blk*cp + c] = sum_{j'} dz[i + j' - 1][co] * w[co][c][2(1-j') + b]
+        k = self.ks
+        return self.cache.get(("dgrad_s2d", dtype, cinp, cp), w, lambda: ops.weight_pack(
+            w.detach(), self.cin, self.cout, 2, k ** 3, self.cin * k ** 3, (k * k, k, 1), (2, 2, 2), (-2, -2, -2),
+            dtype, cinp=cinp, coutp=8 * cp, s2d_mode=2, s2d_cp=cp))
+
     def out_extent(self, e):
         if self.kind == "deconv2":
             return 2 * e
@@ -161,17 +194,33 @@ class ConvFn(Function):
     """z = conv(x0 | x1) + bias  (optionally with fused per-tile channel statistics)."""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, spec: ConvSpec, want_stats: bool):
+    def forward(ctx, x0, x1, weight, bias, spec: ConvSpec, want_stats: bool, zero_bias_grad: bool = False,
+                s2d_cp: int = 0):
         x0 = ops.as_act(x0)
         x1 = ops.as_act(x1) if x1 is not None else None
         n, di, hi, wi, c0 = x0.shape
         c1 = x1.shape[4] if x1 is not None else 0
         dtype, dev = x0.dtype, x0.device
         cp = round_up(spec.cout, 16)
-        do_, ho, wo = (spec.out_extent(e) for e in (di, hi, wi))
+        ctx.s2d_cp = s2d_cp
+        if s2d_cp:
+            # x0 is S(a): the k4 s2 p1 convolution of a == dense k2 s1 p0 convolution of S(a)
+            assert spec.kind == "conv" and spec.ks == 4 and spec.stride == 2 and spec.pad == 1 and x1 is None
+            assert c0 == 8 * s2d_cp
+            do_, ho, wo = di - 1, hi - 1, wi - 1
+        else:
+            do_, ho, wo = (spec.out_extent(e) for e in (di, hi, wi))
         out = ops.new_act(n, do_, ho, wo, cp, dtype, dev)
         part = None
-        if spec.kind == "conv":
+        if s2d_cp:
+            wp, coutp, _ = spec.w_fwd_s2d(weight, dtype, s2d_cp)
+            bp = _padded(bias, coutp)
+            if want_stats:
+                tiles, _ = ops.conv_num_tiles(x0, None, wp, coutp, 2, 1, (0, 0, 0), out, (do_, ho, wo))
+                part = torch.empty((tiles, 2, coutp), dtype=torch.float32, device=dev)
+            ops.conv_fwd(x0, None, wp, coutp, bp, 2, 1, (0, 0, 0), out, (do_, ho, wo), stats=part,
+                         real=(spec.cin, spec.cout))
+        elif spec.kind == "conv":
             wp, coutp, _ = spec.w_fwd(weight, dtype, c0 + c1)
             bp = _padded(bias, coutp)
             pad3 = (spec.pad,) * 3
@@ -190,6 +239,9 @@ class ConvFn(Function):
         ctx.save_for_backward(x0, x1, weight)
         ctx.spec = spec
         ctx.has_bias = bias is not None
+        # a normalisation with batch/instance statistics follows: the mean subtraction cancels the bias,
+        # so its gradient is identically zero and is returned as exact zeros (no reduction pass)
+        ctx.zero_bias_grad = zero_bias_grad
         if part is None:
             part = torch.empty((0,), dtype=torch.float32, device=dev)
         ctx.mark_non_differentiable(part)
@@ -211,7 +263,10 @@ class ConvFn(Function):
         need_dx = ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1])
         if need_dx:
             dxc = ops.new_act(n, di, hi, wi, c0 + c1, dtype, dev)
-            if spec.kind == "conv" and spec.stride == 1:
+            if ctx.s2d_cp:
+                wp, coutp, _ = spec.w_dgrad_s2d(weight, dtype, cg, ctx.s2d_cp)
+                ops.conv_fwd(dz, None, wp, coutp, None, 2, 1, (1, 1, 1), dxc, (di, hi, wi), real=(spec.cout, spec.cin))
+            elif spec.kind == "conv" and spec.stride == 1:
                 wp, coutp, _ = spec.w_dgrad_s1(weight, dtype, cg, c0 + c1)
                 ops.conv_fwd(dz, None, wp, coutp, None, k, 1, (k - 1 - spec.pad,) * 3, dxc, (di, hi, wi),
                              real=(spec.cout, spec.cin))
@@ -230,7 +285,10 @@ class ConvFn(Function):
             dx1 = dxc[..., c0:] if c1 else None
         if ctx.needs_input_grad[2]:
             dw = torch.empty_like(weight, dtype=torch.float32)
-            if spec.kind == "conv":
+            if ctx.s2d_cp:
+                ops.conv_wgrad(x0, None, dz, (do_, ho, wo), 1, (0, 0, 0), 2, 1, (0, 0, 0), dw, spec.cout, spec.cin,
+                               spec.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (2, 2, 2), s2d_cp=ctx.s2d_cp)
+            elif spec.kind == "conv":
                 ops.conv_wgrad(x0, x1, dz, (do_, ho, wo), 1, (0, 0, 0), k, spec.stride, (spec.pad,) * 3, dw,
                                spec.cout, spec.cin, spec.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (1, 1, 1))
             else:
@@ -238,8 +296,11 @@ class ConvFn(Function):
                     ops.conv_wgrad(x0, None, dz, (di, hi, wi), 2, cls, 1, 1, (0, 0, 0), dw,
                                    spec.cout, spec.cin, 8, spec.cout * 8, (4, 2, 1), cls, (0, 0, 0))
         if ctx.has_bias and ctx.needs_input_grad[3]:
-            db = ops.colsum(dz)[: spec.cout].contiguous()
-        return dx0, dx1, dw, db, None, None
+            if ctx.zero_bias_grad:
+                db = torch.zeros((spec.cout,), dtype=torch.float32, device=dev)
+            else:
+                db = ops.colsum(dz)[: spec.cout].contiguous()
+        return dx0, dx1, dw, db, None, None, None, None
 
 
 # ====================================================================================== norm + act
@@ -258,7 +319,8 @@ class NormActFn(Function):
     """a = LeakyReLU(Dropout(Norm(z)))  -- MONAI ADN "NDA" / BatchNorm3d + LeakyReLU."""
 
     @staticmethod
-    def forward(ctx, z, part, gamma, beta, conv_bias, cfg: NormCfg, training, running_mean, running_var):
+    def forward(ctx, z, part, gamma, beta, conv_bias, cfg: NormCfg, training, running_mean, running_var,
+                s2d_out: bool = False):
         z = ops.as_act(z)
         n, d, h, w, c = z.shape
         rows = n * d * h * w
@@ -294,7 +356,12 @@ class NormActFn(Function):
         gp, bp = _padded(gamma, c), _padded(beta, c)
         p = cfg.p if training else 0.0
         seed = _draw_seed() if p > 0.0 else 0
-        a = ops.normact_fwd(z, groups, mean, rstd, gp, bp, cfg.slope, p, seed)
+        if s2d_out:
+            out = torch.zeros(ops.s2d_shape(n, d, h, w, c), dtype=z.dtype, device=z.device)
+            a = ops.normact_fwd(z, groups, mean, rstd, gp, bp, cfg.slope, p, seed, out=out, s2d=True)
+        else:
+            a = ops.normact_fwd(z, groups, mean, rstd, gp, bp, cfg.slope, p, seed)
+        ctx.s2d_out = s2d_out
         ctx.save_for_backward(z, mean, rstd, gp, bp)
         ctx.meta = (groups, cfg.slope, p, seed, batch_stats, gamma.numel() if gamma is not None else 0)
         return a
@@ -307,10 +374,10 @@ class NormActFn(Function):
         da = ops.as_act(da)
         want_affine = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
         dz, dgamma, dbeta = ops.normact_bwd(z, da, groups, mean, rstd, gp, bp, slope, p, seed, batch_stats,
-                                            want_affine and mean is not None)
+                                            want_affine and mean is not None, s2d=ctx.s2d_out)
         dg = dgamma[:nch].contiguous() if (dgamma is not None and ctx.needs_input_grad[2]) else None
         dbt = dbeta[:nch].contiguous() if (dbeta is not None and ctx.needs_input_grad[3]) else None
-        return dz, None, dg, dbt, None, None, None, None, None
+        return dz, None, dg, dbt, None, None, None, None, None, None
 
 
 # ====================================================================================== pool / loss

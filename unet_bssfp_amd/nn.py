@@ -93,8 +93,8 @@ class Conv3d(_Mi355Module):
             bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
             nn.init.uniform_(self.bias, -bound, bound)
 
-    def forward_act(self, x0, x1=None, want_stats=False):
-        return Fn.ConvFn.apply(x0, x1, self.weight, self.bias, self.spec, want_stats)
+    def forward_act(self, x0, x1=None, want_stats=False, zero_bias_grad=False, s2d_cp=0):
+        return Fn.ConvFn.apply(x0, x1, self.weight, self.bias, self.spec, want_stats, zero_bias_grad, s2d_cp)
 
     def forward(self, x):
         z, _ = self.forward_act(self._to_act(x))
@@ -155,18 +155,21 @@ class DownSampleConv(_Mi355Module):
         self.cfg = Fn.NormCfg("batch" if batchnorm else "none", out_channels, eps=1e-5, momentum=0.1,
                               slope=0.2 if activation else 1.0)
 
-    def forward_act(self, x0, x1=None):
+    def forward_act(self, x0, x1=None, s2d_cp=0, s2d_out=False):
+        """s2d_cp > 0: x0 is the space-to-depth tensor S(a) with s2d_cp channels per block (k4 s2 p1 only);
+        s2d_out: return S(output) for the next k4 s2 p1 block instead of the plain activation."""
         fuse = self.batchnorm and self.training
-        z, part = self.conv.forward_act(x0, x1, want_stats=fuse)
+        z, part = self.conv.forward_act(x0, x1, want_stats=fuse, zero_bias_grad=fuse, s2d_cp=s2d_cp)
         if not (self.batchnorm or self.activation):
+            assert not s2d_out
             return z
         if self.batchnorm:
             a = Fn.NormActFn.apply(z, part if fuse else None, self.bn.weight, self.bn.bias, self.conv.bias,
-                                   self.cfg, self.training, self.bn.running_mean, self.bn.running_var)
+                                   self.cfg, self.training, self.bn.running_mean, self.bn.running_var, s2d_out)
             if self.training:
                 self.bn.num_batches_tracked += 1
             return a
-        return Fn.NormActFn.apply(z, None, None, None, None, self.cfg, self.training, None, None)
+        return Fn.NormActFn.apply(z, None, None, None, None, self.cfg, self.training, None, None, s2d_out)
 
     def forward(self, x):
         return self._from_act(self.forward_act(self._to_act(x)), self.conv.out_channels)
@@ -191,10 +194,19 @@ class Discriminator(_Mi355Module):
     def forward(self, x, y):
         ops.require_cuda(x, y)
         cin = x.shape[1] + y.shape[1]
-        h = Fn.PackFn.apply(round_up(cin, 16), self.compute_dtype, x, y)    # torch.cat([x, y], 1) + layout
-        h = self.d1[self.modality].forward_act(h)
-        for blk in (self.d2, self.d3, self.d4, self.d5):
-            h = blk.forward_act(h)
+        cp = round_up(cin, 16)
+        blocks = (self.d1[self.modality], self.d2, self.d3, self.d4, self.d5)
+        if all(e % 32 == 0 for e in x.shape[2:]):
+            # k4 s2 p1 == dense k2 s1 on space-to-depth tensors: every block reads S(prev) and writes
+            # S(own output), so the whole PatchGAN runs on the stride-1 implicit-GEMM kernels
+            h = Fn.PackFn.apply(-cp, self.compute_dtype, x, y)          # cat([x, y], 1) + layout + s2d
+            for i, blk in enumerate(blocks):
+                h = blk.forward_act(h, s2d_cp=cp, s2d_out=i < 4)
+                cp = round_up(blk.conv.out_channels, 16)
+        else:
+            h = Fn.PackFn.apply(cp, self.compute_dtype, x, y)           # torch.cat([x, y], 1) + layout
+            for blk in blocks:
+                h = blk.forward_act(h)
         z, _ = self.final.forward_act(h)
         return Fn.UnpackFn.apply(z, 1)
 
@@ -218,7 +230,7 @@ class Convolution(_Mi355Module):
         self.cfg = Fn.NormCfg("instance", cout, eps=eps, slope=slope, p=float(dropout or 0.0))
 
     def forward_act(self, x0, x1=None):
-        z, part = self.conv.forward_act(x0, x1, want_stats=True)
+        z, part = self.conv.forward_act(x0, x1, want_stats=True, zero_bias_grad=True)
         return Fn.NormActFn.apply(z, part, self.adn.N.weight, self.adn.N.bias, self.conv.bias, self.cfg,
                                   self.training, None, None)
 

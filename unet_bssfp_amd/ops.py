@@ -94,14 +94,39 @@ def unpack_ncdhw(src: torch.Tensor, c: int, coff: int = 0) -> torch.Tensor:
     return out
 
 
+def s2d_shape(n, d, h, w, cblk):
+    """Shape of the space-to-depth tensor S(a) of a plain (n,d,h,w,cblk) activation."""
+    return (n, d // 2 + 1, h // 2 + 1, w // 2 + 1, 8 * cblk)
+
+
+def pack_ncdhw_s2d(src: torch.Tensor, dst: torch.Tensor, cblk: int, coff: int, zero_to: int):
+    """Like pack_ncdhw, but dst is S(a) (pre-zeroed): every plain voxel goes to its (cell, block)."""
+    require_cuda(src, dst)
+    assert src.dtype == torch.float32 and src.is_contiguous() and src.dim() == 5
+    n, c, d, h, w = src.shape
+    _lib.check(_lib.load().mi355_pack_ncdhw_s2d(src.data_ptr(), dst.data_ptr(), n, c, d, h, w, cblk, act_ld(dst), coff,
+                                                zero_to, _DT[dst.dtype], _stream()), "pack_ncdhw_s2d")
+
+
+def unpack_ncdhw_s2d(src: torch.Tensor, c: int, dims, cblk: int, coff: int = 0) -> torch.Tensor:
+    require_cuda(src)
+    n = src.shape[0]
+    d, h, w = dims
+    out = torch.empty((n, c, d, h, w), dtype=torch.float32, device=src.device)
+    _lib.check(_lib.load().mi355_unpack_ncdhw_s2d(src.data_ptr(), out.data_ptr(), n, c, d, h, w, cblk, act_ld(src), coff,
+                                                  _DT[src.dtype], _stream()), "unpack_ncdhw_s2d")
+    return out
+
+
 # ------------------------------------------------------------------------------ weights
 def weight_pack(src: torch.Tensor, cout: int, cin: int, ks: int, s_co: int, s_ci: int,
                 s_k: Sequence[int], tbase: Sequence[int], tstep: Sequence[int], dtype: torch.dtype,
-                cinp: Optional[int] = None) -> Tuple[torch.Tensor, int, int]:
+                cinp: Optional[int] = None, coutp: Optional[int] = None, s2d_mode: int = 0,
+                s2d_cp: int = 0) -> Tuple[torch.Tensor, int, int]:
     """Returns (packed [cinp/16][ks^3][coutp][16], coutp, cinp)."""
     require_cuda(src)
     assert src.dtype == torch.float32 and src.is_contiguous()
-    coutp = round_up(cout, 32)
+    coutp = round_up(cout, 32) if coutp is None else coutp
     cinp = round_up(cin, 16) if cinp is None else cinp
     dst = torch.empty((cinp // 16, ks ** 3, coutp, 16), dtype=dtype, device=src.device)
     d = _lib.WpackDesc()
@@ -112,6 +137,7 @@ def weight_pack(src: torch.Tensor, cout: int, cin: int, ks: int, s_co: int, s_ci
     d.tbase = (C.c_int32 * 3)(*tbase)
     d.tstep = (C.c_int32 * 3)(*tstep)
     d.dtype = _DT[dtype]
+    d.s2d_mode, d.s2d_cp = s2d_mode, s2d_cp
     _lib.check(_lib.load().mi355_weight_pack(C.byref(d), _stream()), "weight_pack")
     return dst, coutp, cinp
 
@@ -166,7 +192,7 @@ def conv_fwd(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os=1, ooff=(0,
 
 
 def conv_wgrad(x0, x1, g, grid, gs, goff, ks, stride, pad, dw, cout, cin, s_co, s_ci, s_k, tbase, tstep,
-               accumulate=False):
+               accumulate=False, s2d_cp=0):
     """dw (torch layout, f32) (+)= sum_p x[p*stride+tap-pad] * g[p*gs+goff]."""
     require_cuda(x0, x1, g, dw)
     assert dw.dtype == torch.float32 and g.dtype == x0.dtype
@@ -192,6 +218,7 @@ def conv_wgrad(x0, x1, g, grid, gs, goff, ks, stride, pad, dw, cout, cin, s_co, 
     d.tstep = (C.c_int32 * 3)(*tstep)
     d.accumulate = 1 if accumulate else 0
     d.dtype = _DT[x0.dtype]
+    d.s2d_cp = s2d_cp
     lib = _lib.load()
     need = lib.mi355_conv_wgrad_workspace(C.byref(d))
     if need < 0:
@@ -248,18 +275,24 @@ def _normact_desc(z, groups, mean, rstd, gamma, beta, slope, drop_p, seed):
     return d
 
 
-def normact_fwd(z, groups, mean, rstd, gamma, beta, slope, drop_p=0.0, seed=0, out=None):
+def normact_fwd(z, groups, mean, rstd, gamma, beta, slope, drop_p=0.0, seed=0, out=None, s2d=False):
+    """s2d=True: `out` is the pre-zeroed space-to-depth tensor S(a) (s2d_shape) instead of a plain one."""
     require_cuda(z, mean, rstd, gamma, beta, out)
     if out is None:
         out = torch.empty(z.shape, dtype=z.dtype, device=z.device)
     d = _normact_desc(z, groups, mean, rstd, gamma, beta, slope, drop_p, seed)
     d.a, d.lda = out.data_ptr(), act_ld(out)
+    if s2d:
+        d.s2d_a = 1
+        d.sd, d.sh, d.sw = z.shape[1:4]
     _lib.check(_lib.load().mi355_normact_fwd(C.byref(d), _stream()), "normact_fwd")
     return out
 
 
-def normact_bwd(z, da, groups, mean, rstd, gamma, beta, slope, drop_p, seed, batch_stats, want_affine_grads):
-    """Returns (dz, dgamma, dbeta).  dgamma/dbeta are f32 [C] (None if there is no norm)."""
+def normact_bwd(z, da, groups, mean, rstd, gamma, beta, slope, drop_p, seed, batch_stats, want_affine_grads,
+                s2d=False):
+    """Returns (dz, dgamma, dbeta).  dgamma/dbeta are f32 [C] (None if there is no norm).
+    s2d=True: `da` is a gradient in space-to-depth layout (the forward wrote S(a))."""
     require_cuda(z, da)
     lib = _lib.load()
     n, dd, h, w, c = z.shape
@@ -269,6 +302,9 @@ def normact_bwd(z, da, groups, mean, rstd, gamma, beta, slope, drop_p, seed, bat
     dz = torch.empty(z.shape, dtype=z.dtype, device=z.device)
     d.dz, d.lddz = dz.data_ptr(), act_ld(dz)
     d.batch_stats = 1 if batch_stats else 0
+    if s2d:
+        d.s2d_da = 1
+        d.sd, d.sh, d.sw = z.shape[1:4]
     dgamma = dbeta = None
     keep = []
     if mean is not None and (batch_stats or want_affine_grads):
