@@ -124,7 +124,7 @@ typedef struct mi355_conv_desc {
 } mi355_conv_desc;
 int mi355_conv_fwd(const mi355_conv_desc* d, void* stream);
 /* which kernel instance mi355_conv_fwd() will launch for this descriptor (for profiling tools):
- * 1000*halo + 100*tile_shape + 10*voxel_subtiles_per_wave + cout_subtiles_per_wave, <0 on error */
+ * 10000*ks + 1000*halo + 100*tile_shape + 10*voxel_subtiles_per_wave + cout_subtiles_per_wave, <0 on error */
 int mi355_conv_plan_id(const mi355_conv_desc* d);
 /* number of spatial tiles (= rows of stats_part) and tiles per sample (0 if tiles span samples) */
 int mi355_conv_num_tiles(const mi355_conv_desc* d, int32_t* tiles, int32_t* tiles_per_sample);
@@ -199,6 +199,9 @@ typedef struct mi355_normact_desc {
    * from a gradient in S layout.  sd/sh/sw = plain extents of z per sample. */
   int32_t s2d_a, s2d_da;
   int32_t sd, sh, sw;
+  /* optional DEVICE pointer to a 64-bit step counter mixed into the dropout seed (`seed` is then a
+   * per-call salt): a launch captured in a hipGraph draws a new mask on every replay */
+  const uint64_t* seed_ptr;
 } mi355_normact_desc;
 int mi355_normact_fwd(const mi355_normact_desc* d, void* stream);
 int mi355_normact_bwd_reduce(const mi355_normact_desc* d, void* stream);
@@ -235,12 +238,14 @@ int mi355_l1_bwd(const float* a, const float* b, int64_t count, const float* gsc
 /* ------------------------------------------------------------------------------------------
  * Fused multi-tensor AdamW -- torch.optim.AdamW(params, lr) with torch defaults
  * (src/model.py:164, 359-361): decoupled weight decay, bias-corrected moments.
- * ptrs: device array of 4*ntensors pointers {param, grad, exp_avg, exp_avg_sq} (all f32),
- * sizes: device array of ntensors element counts; `step` is the 1-based step number.
+ * ptrs: HOST array of 4*ntensors device pointers {param, grad, exp_avg, exp_avg_sq} (all f32),
+ * sizes: HOST array of ntensors element counts (they travel by value in the kernel arguments, so
+ * the launches can be captured into a hipGraph); the 1-based step number is read from DEVICE
+ * memory (`step_dev`) when given, else taken from `step`.
  * ---------------------------------------------------------------------------------------- */
 int mi355_adamw_multi(const void* const* ptrs, const int64_t* sizes, int32_t ntensors,
-                      int64_t max_size, float lr, float beta1, float beta2, float eps,
-                      float weight_decay, int32_t step, void* stream);
+                      float lr, float beta1, float beta2, float eps, float weight_decay,
+                      const int64_t* step_dev, int64_t step, void* stream);
 
 /* layout probe used by the tests: writes lane -> (row, col) maps of the MFMA accumulators */
 int mi355_mfma_selftest(float* out_f32_1024, float* out_bf16_1024, void* stream);

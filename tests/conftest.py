@@ -11,6 +11,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def pytest_configure(config):
+    import torch
+    torch.set_num_threads(min(16, os.cpu_count() or 1))   # CPU references: the GPU box grants ~16 cores
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 

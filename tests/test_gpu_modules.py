@@ -317,9 +317,41 @@ def test_full_size_128_forward_parity_with_oracle(hip):
     ref = R.RefGenerator("bssfp", dropout=0.0).train()
     ref.load_state_dict(g.state_dict())
     x, _ = R.synthetic_batch(1, 128, seed=1234)
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))       # the GPU box grants a 16-core share
     with torch.no_grad():
         y_ref = ref(x)
         y = g.to(DEV).train()(x.to(DEV)).cpu()
     err = (y - y_ref).abs().mean().item()
     assert err <= 1e-4, err
+
+
+def test_hipgraph_replayed_step_equals_eager_step(hip):
+    """GraphedTrainingStep (whole step as one hipGraph) must produce bit-identical parameters to the
+    eager training_step (same kernels, same order), and keep AdamW's bias correction and the dropout
+    counter advancing on the device."""
+    import unet_bssfp_amd as M
+    from unet_bssfp_amd.functional import DropoutState
+    from unet_bssfp_amd.gan import GraphedTrainingStep, bSSFPToDWITensorModel, synthetic_batch
+
+    def build():
+        torch.manual_seed(4)
+        DropoutState.reset()
+        gen, discr = M.Generator("bssfp", dropout=0.05), M.Discriminator("bssfp")
+        return bSSFPToDWITensorModel("bssfp", gen=gen.to(DEV), discr=discr.to(DEV)).train()
+
+    batch = synthetic_batch(2, 32, seed=9, device=DEV)
+    eager = build()
+    for i in range(4):
+        eager.training_step(batch, i)
+    graphed = build()
+    gs = GraphedTrainingStep(graphed, batch, warmup=2)         # 2 eager warm-up steps, then capture (records, does not run)
+    gs()                                                       # replay = step 3
+    gs()                                                       # replay = step 4
+    torch.cuda.synchronize()
+    for (n, p), (_, q) in zip(eager.named_parameters(), graphed.named_parameters()):
+        assert torch.equal(p, q), n
+    for k in ("gen_loss", "discr_loss"):
+        assert float(eager.last_logs[k]) == float(graphed.last_logs[k])
+    g_opt, _ = graphed.optimizers()
+    g_opt.sync_step_counts()
+    assert g_opt.state[graphed.gen.blocks["unet"].final_conv.weight]["step"] == 4

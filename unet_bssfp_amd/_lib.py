@@ -50,7 +50,7 @@ class NormActDesc(C.Structure):
                 ("slope", _f32), ("drop_p", _f32), ("seed", _u64), ("dtype", _i32),
                 ("da", _vp), ("ldda", _i32), ("dz", _vp), ("lddz", _i32),
                 ("part", _vp), ("blocks_per_group", _i32), ("sums", _vp), ("batch_stats", _i32),
-                ("s2d_a", _i32), ("s2d_da", _i32), ("sd", _i32), ("sh", _i32), ("sw", _i32)]
+                ("s2d_a", _i32), ("s2d_da", _i32), ("sd", _i32), ("sh", _i32), ("sw", _i32), ("seed_ptr", _vp)]
 
 
 _SIGNATURES = {
@@ -79,7 +79,7 @@ _SIGNATURES = {
     "mi355_l1_blocks": (_i32, [_i64]),
     "mi355_l1_fwd": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "mi355_l1_bwd": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
-    "mi355_adamw_multi": (C.c_int, [_vp, _vp, _i32, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
+    "mi355_adamw_multi": (C.c_int, [_vp, _vp, _i32, _f32, _f32, _f32, _f32, _f32, _vp, _i64, _vp]),
     "mi355_mfma_selftest": (C.c_int, [_vp, _vp, _vp]),
 }
 

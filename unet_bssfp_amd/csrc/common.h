@@ -115,6 +115,13 @@ __device__ __forceinline__ void mma16(const Frag<bf16_t>& a, const Frag<bf16_t>&
                                                 __builtin_bit_cast(bf16x8, b.v), acc, 0, 0, 0);
 }
 
+// 16-byte streaming (non-temporal) load: data used once per workgroup should not evict re-used lines
+__device__ __forceinline__ uint4 ld_stream16(const char* p) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // accumulator register i of lane half h holds D[row][col = lane & 31]
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 

@@ -130,7 +130,7 @@ extern "C" int mi355_conv_plan_id(const mi355_conv_desc* d) {
   Plan p;
   int rc = make_plan(d, &p);
   if (rc) return rc;
-  return 1000 * (p.halo ? 1 : 0) + 100 * p.shape + 10 * p.vt + p.ct;
+  return 10000 * d->ks + 1000 * (p.halo ? 1 : 0) + 100 * p.shape + 10 * p.vt + p.ct;
 }
 
 extern "C" int mi355_conv_num_tiles(const mi355_conv_desc* d, int32_t* tiles, int32_t* tiles_per_sample) {

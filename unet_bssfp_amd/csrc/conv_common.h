@@ -89,3 +89,84 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[V
     }
   }
 }
+
+// Epilogue of the halo kernel: subtile row m = acc_row(i, h) sits at (m / TW, m % TW) of the subtile's
+// RS x TW patch, so its output address is base + (m / TW) * hstride + (m % TW) * wstride with
+// compile-time m / TW and (m % TW) - 4h: no shuffles, one 64-bit add per row.
+template <int VT> struct TileOut {
+  long long base[VT]; long long hstride, wstride;
+  bool dvalid[VT]; int hleft[VT], wleft[VT];
+};
+struct TileOutDyn { long long hstride, wstride; };
+
+template <typename T, int VT, int CT, int TW, typename TO>
+__device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, f32x16 (&acc)[VT][CT], const TO& to, int co_base,
+                                                   int tile_index, float* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  float s1[CT], s2[CT], bias[CT];
+  T* yp[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    s1[ct] = 0.f; s2[ct] = 0.f;
+    const int co = co_base + ct * 32 + r;
+    bias[ct] = (a.bias && co < a.cstore) ? a.bias[co] : 0.f;
+    yp[ct] = co < a.cstore ? reinterpret_cast<T*>(a.y) + co : nullptr;
+  }
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt) {
+    if (!to.dvalid[vt]) continue;
+    // running row offset (one add per row, nothing loop-invariant to keep in registers)
+    long long off = to.base[vt] + (long long)(4 * h) * to.wstride;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int m0 = (i & 3) + 8 * (i >> 2);          // row index without the lane-half term 4h (never carries)
+      const int rh = m0 / TW, cw = m0 % TW;
+      if (i > 0) {
+        const int pm = ((i - 1) & 3) + 8 * ((i - 1) >> 2);
+        const int drh = rh - pm / TW, dcw = cw - pm % TW;
+        off += drh * to.hstride + dcw * to.wstride;
+      }
+      if (rh < to.hleft[vt] && cw + 4 * h < to.wleft[vt]) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const float v = acc[vt][ct][i];
+          s1[ct] += v;
+          s2[ct] += v * v;
+          if (yp[ct]) Elem<T>::store(yp[ct] + off, v + bias[ct]);
+        }
+      }
+    }
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      s1[ct] += __shfl_xor(s1[ct], 32, 64);
+      s2[ct] += __shfl_xor(s2[ct], 32, 64);
+    }
+    __syncthreads();
+    if (h == 0) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        red[((wave * CT + ct) * 2 + 0) * 32 + r] = s1[ct];
+        red[((wave * CT + ct) * 2 + 1) * 32 + r] = s2[ct];
+      }
+    }
+    __syncthreads();
+    if (wave == 0 && h == 0) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          t1 += red[((w * CT + ct) * 2 + 0) * 32 + r];
+          t2 += red[((w * CT + ct) * 2 + 1) * 32 + r];
+        }
+        const int co = co_base + ct * 32 + r;
+        float* p = a.stats + ((long long)tile_index * 2) * a.coutp;
+        p[co] = t1;
+        p[a.coutp + co] = t2;
+      }
+    }
+  }
+}

@@ -34,26 +34,33 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-
-  int t = blockIdx.x;
-  const int tw_i = t % a.tiles_w; t /= a.tiles_w;
-  const int th_i = t % a.tiles_h; t /= a.tiles_h;
-  const int td_i = t % a.tiles_d;
-  const int n = t / a.tiles_d;
-  const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
   const int co_base = blockIdx.y * (32 * CT);
 
-  // ---- staging plan: which input voxel each of this thread's 16-B pieces comes from ----
-  int gvox[NP];
+  int tile = blockIdx.x;
+  // halo position of each of this thread's 16-B pieces, packed (hd << 16 | hh << 8 | hw): tile-invariant
+  int hpos[NP];
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int p = tid + i * 256;
     const int vox = p / PPV;
-    const int hw = vox % HW, hh = (vox / HW) % HH, hd = vox / (HW * HH);
-    const int gd = d0 + hd - a.pd, gh = h0 + hh - a.ph, gw = w0 + hw - a.pw;
-    const bool ok = p < NPIECE && gd >= 0 && gd < a.di && gh >= 0 && gh < a.hi && gw >= 0 && gw < a.wi;
-    gvox[i] = ok ? ((n * a.di + gd) * a.hi + gh) * a.wi + gw : -1;
+    hpos[i] = p < NPIECE ? (((vox / (HW * HH)) << 16) | (((vox / HW) % HH) << 8) | (vox % HW)) : -1;
   }
+  int gvox[NP];
+  int tn, d0, h0, w0;                         // origin of the tile whose loads are being issued
+  auto plan_tile = [&](int t) {
+    const int tw_i = t % a.tiles_w; t /= a.tiles_w;
+    const int th_i = t % a.tiles_h; t /= a.tiles_h;
+    const int td_i = t % a.tiles_d;
+    tn = t / a.tiles_d;
+    d0 = td_i * TD; h0 = th_i * TH; w0 = tw_i * TW;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int hp = hpos[i];
+      const int gd = d0 + (hp >> 16) - a.pd, gh = h0 + ((hp >> 8) & 255) - a.ph, gw = w0 + (hp & 255) - a.pw;
+      const bool ok = hp >= 0 && gd >= 0 && gd < a.di && gh >= 0 && gh < a.hi && gw >= 0 && gw < a.wi;
+      gvox[i] = ok ? ((tn * a.di + gd) * a.hi + gh) * a.wi + gw : -1;
+    }
+  };
   uint4 stage[NP];
   auto load_chunk = [&](int c) {
     const int cb = c * 16;
@@ -64,7 +71,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int part = (tid + i * 256) % PPV;
-      if (gvox[i] >= 0)
+      if (gvox[i] >= 0)   // (a non-temporal load here was measured slower: halo overlap re-reads then miss L2)
         stage[i] = *reinterpret_cast<const uint4*>(src + ((long long)gvox[i] * ld + cbase) * ES + part * 16);
       else
         stage[i] = make_uint4(0, 0, 0, 0);
@@ -97,6 +104,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[vt][ct][i] = 0.f;
 
+  plan_tile(tile);
   load_chunk(0);
   for (int c = 0; c < a.nchunks; ++c) {
     __syncthreads();                 // previous chunk's LDS reads are done
@@ -104,8 +112,8 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a) {
     __syncthreads();
     if (c + 1 < a.nchunks) load_chunk(c + 1);   // in flight under the MFMAs
     const char* wc = wlane + (long long)c * NTAP * wtap;
-    // weight fragments are fetched PG taps at a time (all loads of a group in flight together,
-    // one L2 latency per group instead of one per tap); bf16: a whole kd-plane, f32: one kw-row
+    // weight fragments are fetched PG taps at a time (all loads of a group in flight together);
+    // the group size was measured irrelevant (3 / 9 / 27): the L2-resident weights are not the limiter
     constexpr int PG = (ES == 2) ? (KS == 3 ? 9 : NTAP) : KS;
 #pragma unroll
     for (int g0 = 0; g0 < NTAP; g0 += PG) {
@@ -130,18 +138,20 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a) {
     }
   }
 
-  // ---- epilogue ----
-  long long yoff[VT];
+  // ---- epilogue (rows of a subtile are an affine function of the accumulator index) ----
+  TileOut<VT> to;
+  to.hstride = (long long)a.os * a.wy * a.ldy;
+  to.wstride = (long long)a.os * a.ldy;
 #pragma unroll
   for (int vt = 0; vt < VT; ++vt) {
     const int s = wave * VT + vt;
-    const int gd = d0 + s / SPD, gh = h0 + (s % SPD) * RS + r / TW, gw = w0 + r % TW;
-    const bool ok = gd < a.do_ && gh < a.ho && gw < a.wo;
-    yoff[vt] = ok ? ((((long long)n * a.dy + (gd * a.os + a.od)) * a.hy + (gh * a.os + a.oh)) * a.wy +
-                     (gw * a.os + a.ow)) * a.ldy
-                  : -1;
+    const int gd = d0 + s / SPD, gh = h0 + (s % SPD) * RS, gw = w0;
+    to.base[vt] = ((((long long)tn * a.dy + (gd * a.os + a.od)) * a.hy + (gh * a.os + a.oh)) * a.wy + (gw * a.os + a.ow)) * a.ldy;
+    to.dvalid[vt] = gd < a.do_;
+    to.hleft[vt] = a.ho - gh;           // rows with index < hleft are inside
+    to.wleft[vt] = a.wo - gw;
   }
-  conv_epilogue<T, VT, CT>(a, acc, yoff, co_base, blockIdx.x, reinterpret_cast<float*>(smem));
+  conv_epilogue_tile<T, VT, CT, TW>(a, acc, to, co_base, tile, reinterpret_cast<float*>(smem));
 }
 
 template <typename T, int KS, int TD, int TH, int TW>

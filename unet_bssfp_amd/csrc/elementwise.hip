@@ -211,6 +211,11 @@ __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------ norm + dropout + LeakyReLU
+// effective seed: a per-call salt, optionally combined with a step counter kept in device memory (so
+// that a launch captured in a hipGraph draws a new mask on every replay)
+__device__ __forceinline__ unsigned long long eff_seed(unsigned long long salt, const unsigned long long* p) {
+  return p ? p[0] * 0x9E3779B97F4A7C15ull + salt * 0xD1B54A32D192ED03ull + 1ull : salt;
+}
 // keep-mask of element `idx` (logical index, independent of ld): 16 bits of a 32-bit mix
 __device__ __forceinline__ bool drop_keep(unsigned long long seed, unsigned long long idx, unsigned thr16) {
   const unsigned long long pair = idx >> 1;
@@ -226,7 +231,7 @@ struct NormActArgs {
   const char* z; int ldz; char* a; int lda;
   int c; long long rows_per_group; int groups;
   const float* mean; const float* rstd; const float* gamma; const float* beta;
-  float slope; float drop_scale; unsigned thr16; unsigned long long seed;
+  float slope; float drop_scale; unsigned thr16; unsigned long long seed; const unsigned long long* seed_ptr;
   const char* da; int ldda; char* dz; int lddz;
   float* part; int blocks_per_group; const float* sums; int batch_stats;
   S2D s2d_a;      // forward: write `a` in space-to-depth layout
@@ -241,6 +246,7 @@ __global__ __launch_bounds__(256) void normact_fwd_kernel(const NormActArgs q) {
   const int piece = threadIdx.x % lpr, rsub = threadIdx.x / lpr;
   if (rsub >= rpp) return;
   const int ch0 = piece * EPV;
+  const unsigned long long seed = q.thr16 ? eff_seed(q.seed, q.seed_ptr) : 0ull;
   float sc[EPV], sh[EPV];
 #pragma unroll
   for (int j = 0; j < EPV; ++j) {
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(256) void normact_fwd_kernel(const NormActArgs q) {
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
       float t = v.f[j] * sc[j] + sh[j];
-      if (q.thr16) t = drop_keep(q.seed, e0 + j, q.thr16) ? t * q.drop_scale : 0.f;
+      if (q.thr16) t = drop_keep(seed, e0 + j, q.thr16) ? t * q.drop_scale : 0.f;
       v.f[j] = t > 0.f ? t : t * q.slope;
     }
     if (q.s2d_a.d) v.store(reinterpret_cast<T*>(q.a) + s2d_offset(q.s2d_a, (long long)g * q.rows_per_group + row, q.lda) + ch0);
@@ -284,13 +290,14 @@ __device__ __forceinline__ void load_bwd_const(const NormActArgs& q, int g, int 
   }
 }
 // g = da * dropout * lrelu'(pre);  xhat = (z - mean) * rstd  (xhat = z when there is no norm)
-__device__ __forceinline__ void bwd_elem(const NormActArgs& q, float mu, float rs, float ga, float be, float zv,
-                                         float dav, unsigned long long eidx, float& gout, float& xhat) {
+__device__ __forceinline__ void bwd_elem(const NormActArgs& q, unsigned long long seed, float mu, float rs, float ga,
+                                         float be, float zv, float dav, unsigned long long eidx, float& gout,
+                                         float& xhat) {
   xhat = (zv - mu) * rs;
   float pre = xhat * ga + be;
   float gv = dav;
   if (q.thr16) {
-    const bool keep = drop_keep(q.seed, eidx, q.thr16);
+    const bool keep = drop_keep(seed, eidx, q.thr16);
     pre = keep ? pre : 0.f;
     gv = keep ? gv * q.drop_scale : 0.f;
   }
@@ -310,6 +317,7 @@ __global__ __launch_bounds__(256) void normact_bwd_reduce_kernel(const NormActAr
   float* out = q.part + ((long long)g * q.blocks_per_group + b) * 2 * q.c;
   BwdConst<EPV> k;
   load_bwd_const<EPV>(q, g, (int)(threadIdx.x % (q.c / EPV)) * EPV, k);
+  const unsigned long long seed = q.thr16 ? eff_seed(q.seed, q.seed_ptr) : 0ull;
   block_channel_sums<T>(q.c, r0, r1,
       [&](long long row, int ch0, float* s0, float* s1) {
         Vec16<T> zv, dv;
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(256) void normact_bwd_reduce_kernel(const NormActAr
 #pragma unroll
         for (int j = 0; j < EPV; ++j) {
           float gv, xh;
-          bwd_elem(q, k.mu[j], k.rs[j], k.ga[j], k.be[j], zv.f[j], dv.f[j], e0 + j, gv, xh);
+          bwd_elem(q, seed, k.mu[j], k.rs[j], k.ga[j], k.be[j], zv.f[j], dv.f[j], e0 + j, gv, xh);
           s0[j] += gv;
           s1[j] += gv * xh;
         }
@@ -362,6 +370,7 @@ __global__ __launch_bounds__(256) void normact_bwd_apply_kernel(const NormActArg
   const float inv = 1.f / (float)q.rows_per_group;
   BwdConst<EPV> k;
   load_bwd_const<EPV>(q, g, ch0, k);
+  const unsigned long long seed = q.thr16 ? eff_seed(q.seed, q.seed_ptr) : 0ull;
   float kk[EPV], m0[EPV], m1[EPV];
 #pragma unroll
   for (int j = 0; j < EPV; ++j) {
@@ -384,7 +393,7 @@ __global__ __launch_bounds__(256) void normact_bwd_apply_kernel(const NormActArg
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
       float gv, xh;
-      bwd_elem(q, k.mu[j], k.rs[j], k.ga[j], k.be[j], zv.f[j], dv.f[j], e0 + j, gv, xh);
+      bwd_elem(q, seed, k.mu[j], k.rs[j], k.ga[j], k.be[j], zv.f[j], dv.f[j], e0 + j, gv, xh);
       zv.f[j] = kk[j] * (gv - m0[j] - xh * m1[j]);
     }
     zv.store(ob + row * q.lddz + ch0);
@@ -510,22 +519,33 @@ __global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ a
 }
 
 // ------------------------------------------------------------------ AdamW (multi-tensor)
-__global__ __launch_bounds__(256) void adamw_kernel(const void* const* __restrict__ ptrs,
-                                                    const long long* __restrict__ sizes, float lr, float beta1,
-                                                    float beta2, float eps, float wd, float bc1, float rsqrt_bc2) {
+// Tensor pointers travel BY VALUE in the kernel arguments (chunks of kAdamChunk tensors), so the
+// launch needs no device-side table and can be captured into a hipGraph; the step count is read
+// from device memory when given (a captured launch then advances with its counter).
+constexpr int kAdamChunk = 24;
+struct AdamChunk {
+  float* p[kAdamChunk]; const float* g[kAdamChunk]; float* m[kAdamChunk]; float* v[kAdamChunk];
+  long long n[kAdamChunk];
+};
+__global__ __launch_bounds__(256) void adamw_kernel(const AdamChunk c, float lr, double beta1, double beta2, float eps,
+                                                    float wd, const long long* step_dev, long long step_host) {
   const int t = blockIdx.y;
-  const long long nel = sizes[t];
-  float* p = (float*)ptrs[4 * t];
-  const float* g = (const float*)ptrs[4 * t + 1];
-  float* m = (float*)ptrs[4 * t + 2];
-  float* v = (float*)ptrs[4 * t + 3];
+  const long long nel = c.n[t];
+  float* __restrict__ p = c.p[t];
+  const float* __restrict__ g = c.g[t];
+  float* __restrict__ m = c.m[t];
+  float* __restrict__ v = c.v[t];
+  const double step = (double)(step_dev ? step_dev[0] : step_host);
+  const float bc1 = (float)(1.0 - pow(beta1, step));
+  const float rsqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow(beta2, step)));
+  const float b1 = (float)beta1, b2 = (float)beta2;
   const float step_size = lr / bc1;
   const long long stride = (long long)gridDim.x * 256;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nel; i += stride) {
     const float gi = g[i];
     float pi = p[i] * (1.f - lr * wd);
-    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
-    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
     pi -= step_size * (mi / denom);
     p[i] = pi; m[i] = mi; v[i] = vi;
@@ -654,7 +674,10 @@ int mi355_weight_pack(const mi355_wpack_desc* d, void* stream) {
 }
 
 int32_t mi355_channel_stats_blocks(int64_t rows_per_group) {
-  long long b = (rows_per_group + kRowsPerStatBlock - 1) / kRowsPerStatBlock;
+  // >= 128 rows per block, ~1024 blocks for the big tensors (2048 rows each at 128^3)
+  long long b = rows_per_group / 128;
+  if (b > 1024) b = (rows_per_group + kRowsPerStatBlock - 1) / kRowsPerStatBlock;
+  if (b < 1024 && rows_per_group / 128 > 1024) b = 1024;
   if (b < 1) b = 1;
   if (b > 2048) b = 2048;
   return (int32_t)b;
@@ -703,6 +726,7 @@ static int fill_normact(const mi355_normact_desc* d, NormActArgs* q, const char*
   q->thr16 = d->drop_p > 0.f ? (unsigned)(d->drop_p * 65536.f + 0.5f) : 0u;
   q->drop_scale = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
   q->seed = d->seed;
+  q->seed_ptr = (const unsigned long long*)d->seed_ptr;
   q->da = (const char*)d->da; q->ldda = d->ldda; q->dz = (char*)d->dz; q->lddz = d->lddz;
   q->part = d->part; q->blocks_per_group = d->blocks_per_group; q->sums = d->sums; q->batch_stats = d->batch_stats;
   q->s2d_a = S2D{0, 0, 0, 0};
@@ -823,15 +847,27 @@ int mi355_l1_bwd(const float* a, const float* b, int64_t count, const float* gsc
   return mi355_check_launch("l1_bwd");
 }
 
-int mi355_adamw_multi(const void* const* ptrs, const int64_t* sizes, int32_t ntensors, int64_t max_size, float lr,
-                      float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream) {
-  MI355_REQUIRE(ptrs && sizes && ntensors > 0 && max_size > 0 && step >= 1, "adamw: bad argument");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  long long nb = (max_size + 256 * 4 - 1) / (256 * 4);
-  if (nb > 1024) nb = 1024;
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)nb, ntensors), dim3(256), 0, (hipStream_t)stream, ptrs,
-                     (const long long*)sizes, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)));
+int mi355_adamw_multi(const void* const* ptrs, const int64_t* sizes, int32_t ntensors, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, const int64_t* step_dev, int64_t step,
+                      void* stream) {
+  MI355_REQUIRE(ptrs && sizes && ntensors > 0 && (step_dev || step >= 1), "adamw: bad argument");
+  for (int base = 0; base < ntensors; base += kAdamChunk) {
+    const int cnt = ntensors - base < kAdamChunk ? ntensors - base : kAdamChunk;
+    AdamChunk c;
+    long long mx = 0;
+    for (int i = 0; i < kAdamChunk; ++i) {
+      const int t = base + (i < cnt ? i : 0);
+      c.p[i] = (float*)ptrs[4 * t]; c.g[i] = (const float*)ptrs[4 * t + 1];
+      c.m[i] = (float*)ptrs[4 * t + 2]; c.v[i] = (float*)ptrs[4 * t + 3];
+      c.n[i] = i < cnt ? sizes[t] : 0;
+      MI355_REQUIRE(i >= cnt || (c.p[i] && c.g[i] && c.m[i] && c.v[i] && c.n[i] > 0), "adamw: null tensor %d", t);
+      if (c.n[i] > mx) mx = c.n[i];
+    }
+    long long nb = (mx + 256 * 4 - 1) / (256 * 4);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)nb, cnt), dim3(256), 0, (hipStream_t)stream, c, lr, (double)beta1,
+                       (double)beta2, eps, weight_decay, (const long long*)step_dev, (long long)step);
+  }
   return mi355_check_launch("adamw");
 }
 

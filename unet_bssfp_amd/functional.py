@@ -32,11 +32,13 @@ class LayerCache:
         self._store = {}
 
     def get(self, key, tensor: torch.Tensor, builder):
+        """builder(reuse) -> (packed, coutp, cinp); `reuse` is the previous buffer (re-packed in place so
+        that its address stays stable across steps -- a captured hipGraph keeps pointing at it)."""
         tag = (tensor._version, tensor.data_ptr(), tensor.device, _WEIGHT_EPOCH)
         hit = self._store.get(key)
         if hit is not None and hit[0] == tag:
             return hit[1]
-        val = builder()
+        val = builder(hit[1][0] if hit is not None else None)
         self._store[key] = (tag, val)
         return val
 
@@ -144,45 +146,45 @@ class ConvSpec:
     # ---- packed weights --------------------------------------------------------------
     def w_fwd(self, w, dtype, cinp):
         k = self.ks
-        return self.cache.get(("fwd", dtype, cinp), w, lambda: ops.weight_pack(
+        return self.cache.get(("fwd", dtype, cinp), w, lambda r: ops.weight_pack(
             w.detach(), self.cout, self.cin, k, self.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (1, 1, 1),
-            dtype, cinp))
+            dtype, cinp, reuse=r))
 
     def w_dgrad_s1(self, w, dtype, cinp, coutp_min):
         k = self.ks
-        return self.cache.get(("dgrad", dtype, cinp), w, lambda: ops.weight_pack(
+        return self.cache.get(("dgrad", dtype, cinp), w, lambda r: ops.weight_pack(
             w.detach(), self.cin, self.cout, k, k ** 3, self.cin * k ** 3, (k * k, k, 1), (k - 1,) * 3, (-1,) * 3,
-            dtype, cinp))
+            dtype, cinp, reuse=r))
 
     def w_dgrad_s2(self, w, dtype, cinp, cls):
         # k4 s2 p1 transposed: parity class p per dim uses taps {3,1} (p=0) or {2,0} (p=1)
         k = self.ks
         tb = tuple(3 if p == 0 else 2 for p in cls)
-        return self.cache.get(("dgrad2", dtype, cinp, cls), w, lambda: ops.weight_pack(
-            w.detach(), self.cin, self.cout, 2, k ** 3, self.cin * k ** 3, (k * k, k, 1), tb, (-2,) * 3, dtype, cinp))
+        return self.cache.get(("dgrad2", dtype, cinp, cls), w, lambda r: ops.weight_pack(
+            w.detach(), self.cin, self.cout, 2, k ** 3, self.cin * k ** 3, (k * k, k, 1), tb, (-2,) * 3, dtype, cinp, reuse=r))
 
     def w_deconv_fwd(self, w, dtype, cinp, cls):
         # ConvTranspose3d weight (Cin, Cout, 2,2,2): class = output parity = tap
-        return self.cache.get(("dfwd", dtype, cinp, cls), w, lambda: ops.weight_pack(
-            w.detach(), self.cout, self.cin, 1, 8, self.cout * 8, (4, 2, 1), cls, (0, 0, 0), dtype, cinp))
+        return self.cache.get(("dfwd", dtype, cinp, cls), w, lambda r: ops.weight_pack(
+            w.detach(), self.cout, self.cin, 1, 8, self.cout * 8, (4, 2, 1), cls, (0, 0, 0), dtype, cinp, reuse=r))
 
     def w_deconv_dgrad(self, w, dtype, cinp):
-        return self.cache.get(("ddgrad", dtype, cinp), w, lambda: ops.weight_pack(
-            w.detach(), self.cin, self.cout, 2, self.cout * 8, 8, (4, 2, 1), (0, 0, 0), (1, 1, 1), dtype, cinp))
+        return self.cache.get(("ddgrad", dtype, cinp), w, lambda r: ops.weight_pack(
+            w.detach(), self.cin, self.cout, 2, self.cout * 8, 8, (4, 2, 1), (0, 0, 0), (1, 1, 1), dtype, cinp, reuse=r))
 
     # k4 s2 p1 on a space-to-depth input (dense k2 s1): W'[j][co][blk*cp + c] = w[co][c][2j + b]
     def w_fwd_s2d(self, w, dtype, cp):
         k = self.ks
-        return self.cache.get(("fwd_s2d", dtype, cp), w, lambda: ops.weight_pack(
+        return self.cache.get(("fwd_s2d", dtype, cp), w, lambda r: ops.weight_pack(
             w.detach(), self.cout, self.cin, 2, self.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (2, 2, 2),
-            dtype, cinp=8 * cp, s2d_mode=1, s2d_cp=cp))
+            dtype, cinp=8 * cp, s2d_mode=1, s2d_cp=cp, reuse=r))
 
     def w_dgrad_s2d(self, w, dtype, cinp, cp):
         # dS[i][blk*cp + c] = sum_{j'} dz[i + j' - 1][co] * w[co][c][2(1-j') + b]
         k = self.ks
-        return self.cache.get(("dgrad_s2d", dtype, cinp, cp), w, lambda: ops.weight_pack(
+        return self.cache.get(("dgrad_s2d", dtype, cinp, cp), w, lambda r: ops.weight_pack(
             w.detach(), self.cin, self.cout, 2, k ** 3, self.cin * k ** 3, (k * k, k, 1), (2, 2, 2), (-2, -2, -2),
-            dtype, cinp=cinp, coutp=8 * cp, s2d_mode=2, s2d_cp=cp))
+            dtype, cinp=cinp, coutp=8 * cp, s2d_mode=2, s2d_cp=cp, reuse=r))
 
     def out_extent(self, e):
         if self.kind == "deconv2":
@@ -310,9 +312,36 @@ class NormCfg:
         self.kind, self.channels, self.eps, self.momentum, self.slope, self.p = kind, channels, eps, momentum, slope, p
 
 
-def _draw_seed() -> int:
-    # host-side draw from torch's CPU generator: reproducible under torch.manual_seed, no device sync
-    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+class DropoutState:
+    """Dropout randomness without host involvement per launch: one 64-bit step counter per device in
+    device memory (seeded from torch's CPU generator, so torch.manual_seed governs it) plus a per-call
+    salt.  ``advance()`` (once per training step) bumps the counter ON THE DEVICE, so a step captured
+    in a hipGraph draws fresh masks at every replay."""
+    _base = {}
+    _salt = 0
+
+    @classmethod
+    def base(cls, device) -> torch.Tensor:
+        t = cls._base.get(device)
+        if t is None:
+            t = torch.randint(0, 2 ** 40, (1,), dtype=torch.int64).to(device)
+            cls._base[device] = t
+        return t
+
+    @classmethod
+    def next_salt(cls) -> int:
+        cls._salt += 1
+        return cls._salt
+
+    @classmethod
+    def advance(cls, device):
+        cls.base(device).add_(1)
+        cls._salt = 0
+
+    @classmethod
+    def reset(cls):
+        cls._base.clear()
+        cls._salt = 0
 
 
 class NormActFn(Function):
@@ -355,13 +384,15 @@ class NormActFn(Function):
                 rstd = torch.rsqrt(_padded(running_var, c, 1.0) + cfg.eps).reshape(1, c)
         gp, bp = _padded(gamma, c), _padded(beta, c)
         p = cfg.p if training else 0.0
-        seed = _draw_seed() if p > 0.0 else 0
+        seed = DropoutState.next_salt() if p > 0.0 else 0
+        seed_t = DropoutState.base(z.device) if p > 0.0 else None
         if s2d_out:
             out = torch.zeros(ops.s2d_shape(n, d, h, w, c), dtype=z.dtype, device=z.device)
-            a = ops.normact_fwd(z, groups, mean, rstd, gp, bp, cfg.slope, p, seed, out=out, s2d=True)
+            a = ops.normact_fwd(z, groups, mean, rstd, gp, bp, cfg.slope, p, seed, out=out, s2d=True, seed_t=seed_t)
         else:
-            a = ops.normact_fwd(z, groups, mean, rstd, gp, bp, cfg.slope, p, seed)
+            a = ops.normact_fwd(z, groups, mean, rstd, gp, bp, cfg.slope, p, seed, seed_t=seed_t)
         ctx.s2d_out = s2d_out
+        ctx.seed_t = seed_t
         ctx.save_for_backward(z, mean, rstd, gp, bp)
         ctx.meta = (groups, cfg.slope, p, seed, batch_stats, gamma.numel() if gamma is not None else 0)
         return a
@@ -374,7 +405,7 @@ class NormActFn(Function):
         da = ops.as_act(da)
         want_affine = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
         dz, dgamma, dbeta = ops.normact_bwd(z, da, groups, mean, rstd, gp, bp, slope, p, seed, batch_stats,
-                                            want_affine and mean is not None, s2d=ctx.s2d_out)
+                                            want_affine and mean is not None, s2d=ctx.s2d_out, seed_t=ctx.seed_t)
         dg = dgamma[:nch].contiguous() if (dgamma is not None and ctx.needs_input_grad[2]) else None
         dbt = dbeta[:nch].contiguous() if (dbeta is not None and ctx.needs_input_grad[3]) else None
         return dz, None, dg, dbt, None, None, None, None, None, None

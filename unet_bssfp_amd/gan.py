@@ -114,32 +114,47 @@ class bSSFPToDWITensorModel(nn.Module):
         for p in module.parameters():
             p.requires_grad_(flag)
 
-    def training_step(self, batch, batch_idx=0):
+    # The step is split at the two points where gradients cross ranks, so that it can run eagerly
+    # (training_step) or as hipGraph segments with the collectives in between (GraphedTrainingStep).
+    def _phase_gen(self, batch, logs):
+        """toggle(gen_opt) -> _gen_step -> manual_backward          (src/model.py:264-268)"""
         x, y = self.unpack_batch(batch)
-        gen_opt, discr_opt = self.optimizers()
-        logs: Dict[str, torch.Tensor] = {}
-
-        # ---- generator phase
+        if x.is_cuda:
+            from .functional import DropoutState
+            DropoutState.advance(x.device)
         self._toggle(self.discr, False)
         loss, _ = self._gen_step(x, y, logs)
         logs["gen_loss"] = loss.detach()
         loss.backward()
-        if self.grad_sync_gen is not None:
-            self.grad_sync_gen.finish()
+
+    def _phase_gen_update_discr(self, batch, logs):
+        """gen_opt.step/zero_grad/untoggle -> toggle(discr_opt) -> _discr_step -> manual_backward  (:269-278)"""
+        x, y = self.unpack_batch(batch)
+        gen_opt, _ = self.optimizers()
         gen_opt.step()
         gen_opt.zero_grad()
         self._toggle(self.discr, True)
-
-        # ---- discriminator phase
         self._toggle(self.gen, False)
         loss = self._discr_step(x, y)
         logs["discr_loss"] = loss.detach()
         loss.backward()
-        if self.grad_sync_discr is not None:
-            self.grad_sync_discr.finish()
+
+    def _phase_discr_update(self):
+        """discr_opt.step/zero_grad/untoggle                          (:279-281)"""
+        _, discr_opt = self.optimizers()
         discr_opt.step()
         discr_opt.zero_grad()
         self._toggle(self.gen, True)
+
+    def training_step(self, batch, batch_idx=0):
+        logs: Dict[str, torch.Tensor] = {}
+        self._phase_gen(batch, logs)
+        if self.grad_sync_gen is not None:
+            self.grad_sync_gen.finish()
+        self._phase_gen_update_discr(batch, logs)
+        if self.grad_sync_discr is not None:
+            self.grad_sync_discr.finish()
+        self._phase_discr_update()
         self.last_logs = logs
         return None
 
@@ -147,6 +162,118 @@ class bSSFPToDWITensorModel(nn.Module):
         """The step's scalars as ONE tensor (order: LOG_KEYS) -- a single all-reduce replaces the
         reference's six ``sync_dist`` logs."""
         return torch.stack([self.last_logs[k].reshape(()).float() for k in LOG_KEYS])
+
+
+class GraphedTrainingStep:
+    """The training step as hipGraph replays (HIP graphs instead of ~1 000 eager launches per step).
+
+    world_size 1: the whole step is one graph.  world_size > 1: three graph segments with the two
+    gradient all-reduces (generator, discriminator) issued eagerly between them on flat buffers --
+    the payload (90.6 MB + 44.9 MB f32) is ~1 ms on xGMI against a ~20 ms step, so it is not
+    overlapped here; the hook-driven overlapped path is ``ddp.GradSync`` (eager mode).
+
+    The batch tensors are static inputs: ``load(batch)`` copies new volumes into them.  Dropout masks
+    change per replay (device-side step counter), AdamW bias correction advances on the device.
+    """
+
+    def __init__(self, model: bSSFPToDWITensorModel, batch, warmup: int = 3, group=None):
+        import torch.distributed as dist
+        from .ddp import used_parameters
+        self.model = model
+        self.batch = batch
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if model.grad_sync_gen is not None or model.grad_sync_discr is not None:
+            raise RuntimeError("GraphedTrainingStep does its own gradient exchange: do not ddp.attach() the model")
+        self._gparams = used_parameters(model.gen, model.input_modality)
+        self._dparams = used_parameters(model.discr, model.input_modality)
+        dev = next(model.parameters()).device
+        self._flat_g = torch.zeros(sum(p.numel() for p in self._gparams), device=dev) if self.world > 1 else None
+        self._flat_d = torch.zeros(sum(p.numel() for p in self._dparams), device=dev) if self.world > 1 else None
+        for _ in range(max(2, warmup)):                     # eager: allocations, caches, optimiser state
+            self._eager_step()
+        torch.cuda.synchronize()
+        self.graphs = []
+        logs: Dict[str, torch.Tensor] = {}
+        if self.world == 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                model._phase_gen(batch, logs)
+                model._phase_gen_update_discr(batch, logs)
+                model._phase_discr_update()
+            self.graphs = [g]
+        else:
+            g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                model._phase_gen(batch, logs)
+                self._gather(self._gparams, self._flat_g)
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self._scatter(self._gparams, self._flat_g)
+                model._phase_gen_update_discr(batch, logs)
+                self._gather(self._dparams, self._flat_d)
+            with torch.cuda.graph(g3, pool=g1.pool()):
+                self._scatter(self._dparams, self._flat_d)
+                model._phase_discr_update()
+            self.graphs = [g1, g2, g3]
+        model.last_logs = logs
+        torch.cuda.synchronize()
+
+    # ---- flat gradient buffers (world > 1)
+    @staticmethod
+    def _gather(params, flat):
+        off = 0
+        for p in params:
+            n = p.numel()
+            if p.grad is not None:
+                flat[off:off + n].copy_(p.grad.reshape(-1))
+            else:
+                flat[off:off + n].zero_()
+            off += n
+
+    def _scatter(self, params, flat):
+        flat.mul_(1.0 / self.world)
+        off = 0
+        for p in params:
+            n = p.numel()
+            p.grad = flat[off:off + n].view_as(p)
+            off += n
+
+    def _reduce(self, flat):
+        import torch.distributed as dist
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _eager_step(self):
+        m = self.model
+        logs: Dict[str, torch.Tensor] = {}
+        m._phase_gen(self.batch, logs)
+        if self.world > 1:
+            self._gather(self._gparams, self._flat_g)
+            self._reduce(self._flat_g)
+            self._scatter(self._gparams, self._flat_g)
+        m._phase_gen_update_discr(self.batch, logs)
+        if self.world > 1:
+            self._gather(self._dparams, self._flat_d)
+            self._reduce(self._flat_d)
+            self._scatter(self._dparams, self._flat_d)
+        m._phase_discr_update()
+        m.last_logs = logs
+
+    def load(self, batch):
+        """Copy a new batch into the static input tensors."""
+        for k, v in batch.items():
+            if k in self.batch and isinstance(v, dict) and DATA in v:
+                self.batch[k][DATA].copy_(v[DATA], non_blocking=True)
+
+    def __call__(self):
+        if self.world == 1:
+            self.graphs[0].replay()
+            return
+        g1, g2, g3 = self.graphs
+        g1.replay()
+        self._reduce(self._flat_g)
+        g2.replay()
+        self._reduce(self._flat_d)
+        g3.replay()
 
 
 def synthetic_batch(n: int, s, seed: int, modality: str = "bssfp", device="cpu"):

@@ -122,13 +122,18 @@ def unpack_ncdhw_s2d(src: torch.Tensor, c: int, dims, cblk: int, coff: int = 0) 
 def weight_pack(src: torch.Tensor, cout: int, cin: int, ks: int, s_co: int, s_ci: int,
                 s_k: Sequence[int], tbase: Sequence[int], tstep: Sequence[int], dtype: torch.dtype,
                 cinp: Optional[int] = None, coutp: Optional[int] = None, s2d_mode: int = 0,
-                s2d_cp: int = 0) -> Tuple[torch.Tensor, int, int]:
-    """Returns (packed [cinp/16][ks^3][coutp][16], coutp, cinp)."""
+                s2d_cp: int = 0, reuse: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, int, int]:
+    """Returns (packed [cinp/16][ks^3][coutp][16], coutp, cinp).  `reuse`: re-pack in place into an
+    earlier result (keeps the buffer address stable: required for hipGraph replays)."""
     require_cuda(src)
     assert src.dtype == torch.float32 and src.is_contiguous()
     coutp = round_up(cout, 32) if coutp is None else coutp
     cinp = round_up(cin, 16) if cinp is None else cinp
-    dst = torch.empty((cinp // 16, ks ** 3, coutp, 16), dtype=dtype, device=src.device)
+    shape = (cinp // 16, ks ** 3, coutp, 16)
+    if reuse is not None and tuple(reuse.shape) == shape and reuse.dtype == dtype and reuse.device == src.device:
+        dst = reuse
+    else:
+        dst = torch.empty(shape, dtype=dtype, device=src.device)
     d = _lib.WpackDesc()
     d.src, d.dst = src.data_ptr(), dst.data_ptr()
     d.cout, d.cin, d.coutp, d.cinp, d.ks = cout, cin, coutp, cinp, ks
@@ -263,7 +268,7 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def _normact_desc(z, groups, mean, rstd, gamma, beta, slope, drop_p, seed):
+def _normact_desc(z, groups, mean, rstd, gamma, beta, slope, drop_p, seed, seed_t=None):
     d = _lib.NormActDesc()
     n, dd, h, w, c = z.shape
     rows = n * dd * h * w
@@ -271,16 +276,17 @@ def _normact_desc(z, groups, mean, rstd, gamma, beta, slope, drop_p, seed):
     d.rows_per_group, d.groups = rows // groups, groups
     d.mean, d.rstd, d.gamma, d.beta = _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta)
     d.slope, d.drop_p, d.seed = slope, drop_p, seed
+    d.seed_ptr = _ptr(seed_t)
     d.dtype = _DT[z.dtype]
     return d
 
 
-def normact_fwd(z, groups, mean, rstd, gamma, beta, slope, drop_p=0.0, seed=0, out=None, s2d=False):
+def normact_fwd(z, groups, mean, rstd, gamma, beta, slope, drop_p=0.0, seed=0, out=None, s2d=False, seed_t=None):
     """s2d=True: `out` is the pre-zeroed space-to-depth tensor S(a) (s2d_shape) instead of a plain one."""
     require_cuda(z, mean, rstd, gamma, beta, out)
     if out is None:
         out = torch.empty(z.shape, dtype=z.dtype, device=z.device)
-    d = _normact_desc(z, groups, mean, rstd, gamma, beta, slope, drop_p, seed)
+    d = _normact_desc(z, groups, mean, rstd, gamma, beta, slope, drop_p, seed, seed_t)
     d.a, d.lda = out.data_ptr(), act_ld(out)
     if s2d:
         d.s2d_a = 1
@@ -290,14 +296,14 @@ def normact_fwd(z, groups, mean, rstd, gamma, beta, slope, drop_p=0.0, seed=0, o
 
 
 def normact_bwd(z, da, groups, mean, rstd, gamma, beta, slope, drop_p, seed, batch_stats, want_affine_grads,
-                s2d=False):
+                s2d=False, seed_t=None):
     """Returns (dz, dgamma, dbeta).  dgamma/dbeta are f32 [C] (None if there is no norm).
     s2d=True: `da` is a gradient in space-to-depth layout (the forward wrote S(a))."""
     require_cuda(z, da)
     lib = _lib.load()
     n, dd, h, w, c = z.shape
     rows = n * dd * h * w
-    d = _normact_desc(z, groups, mean, rstd, gamma, beta, slope, drop_p, seed)
+    d = _normact_desc(z, groups, mean, rstd, gamma, beta, slope, drop_p, seed, seed_t)
     d.da, d.ldda = da.data_ptr(), act_ld(da)
     dz = torch.empty(z.shape, dtype=z.dtype, device=z.device)
     d.dz, d.lddz = dz.data_ptr(), act_ld(dz)
