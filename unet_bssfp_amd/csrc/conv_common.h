@@ -99,7 +99,7 @@ template <int VT> struct TileOut {
 };
 struct TileOutDyn { long long hstride, wstride; };
 
-template <typename T, int VT, int CT, int TW, typename TO>
+template <typename T, int VT, int CT, int TW, int NW, typename TO>
 __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, f32x16 (&acc)[VT][CT], const TO& to, int co_base,
                                                    int tile_index, float* red) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -133,7 +133,11 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, f32x16 (&a
           const float v = acc[vt][ct][i];
           s1[ct] += v;
           s2[ct] += v * v;
+#ifdef MI355_EXPERIMENT_NO_STORE
+          asm volatile("" :: "v"(v + bias[ct]));
+#else
           if (yp[ct]) Elem<T>::store(yp[ct] + off, v + bias[ct]);
+#endif
         }
       }
     }
@@ -158,7 +162,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, f32x16 (&a
       for (int ct = 0; ct < CT; ++ct) {
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < NW; ++w) {
           t1 += red[((w * CT + ct) * 2 + 0) * 32 + r];
           t2 += red[((w * CT + ct) * 2 + 1) * 32 + r];
         }

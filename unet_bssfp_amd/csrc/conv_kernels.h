@@ -16,32 +16,39 @@
 #pragma once
 #include "conv_common.h"
 
-template <typename T, int KS, int TD, int TH, int TW, int CT>
-__global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a) {
+template <typename T, int KS, int TD, int TH, int TW, int CT, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void conv_halo_kernel(const ConvArgs a) {
   constexpr int ES = sizeof(T);
   constexpr int RS = 32 / TW;                 // rows (h) per 32-voxel subtile
   constexpr int SPD = TH / RS;                // subtiles per d-slice
   constexpr int NSUB = TD * SPD;
-  constexpr int VT = NSUB / 4;
-  static_assert(NSUB % 4 == 0 && TW * RS == 32 && TH % RS == 0, "tile shape");
+  constexpr int VT = NSUB / NW;
+  constexpr int NTHR = NW * 64;
+  static_assert(NSUB % NW == 0 && TW * RS == 32 && TH % RS == 0, "tile shape");
   constexpr int NTAP = KS * KS * KS;
   constexpr int HD = TD + KS - 1, HH = TH + KS - 1, HW = TW + KS - 1;
   constexpr int VS = 16 * ES + 16;            // LDS bytes per halo voxel (+16: bank spread)
   constexpr int PPV = ES;                     // 16-B pieces per voxel (16 ch * ES / 16)
   constexpr int NPIECE = HD * HH * HW * PPV;
-  constexpr int NP = (NPIECE + 255) / 256;
+  constexpr int NP = (NPIECE + NTHR - 1) / NTHR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int co_base = blockIdx.y * (32 * CT);
 
-  int tile = blockIdx.x;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
+  // range of tiles (neighbouring tiles share halo lines in that XCD's L2).  Bijective for any grid size.
+  int tile;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;
+  }
   // halo position of each of this thread's 16-B pieces, packed (hd << 16 | hh << 8 | hw): tile-invariant
   int hpos[NP];
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
-    const int p = tid + i * 256;
+    const int p = tid + i * NTHR;
     const int vox = p / PPV;
     hpos[i] = p < NPIECE ? (((vox / (HW * HH)) << 16) | (((vox / HW) % HH) << 8) | (vox % HW)) : -1;
   }
@@ -70,17 +77,21 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a) {
     const int cbase = first ? cb : cb - a.c0;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      const int part = (tid + i * 256) % PPV;
+      const int part = (tid + i * NTHR) % PPV;
+#ifdef MI355_EXPERIMENT_NO_STAGE
+      stage[i] = make_uint4(gvox[i], part, cbase, (int)ld);
+#else
       if (gvox[i] >= 0)   // (a non-temporal load here was measured slower: halo overlap re-reads then miss L2)
         stage[i] = *reinterpret_cast<const uint4*>(src + ((long long)gvox[i] * ld + cbase) * ES + part * 16);
       else
         stage[i] = make_uint4(0, 0, 0, 0);
+#endif
     }
   };
   auto store_chunk = [&]() {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      const int p = tid + i * 256;
+      const int p = tid + i * NTHR;
       if (p < NPIECE) *reinterpret_cast<uint4*>(smem + (p / PPV) * VS + (p % PPV) * 16) = stage[i];
     }
   };
@@ -115,6 +126,9 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a) {
     // weight fragments are fetched PG taps at a time (all loads of a group in flight together);
     // the group size was measured irrelevant (3 / 9 / 27): the L2-resident weights are not the limiter
     constexpr int PG = (ES == 2) ? (KS == 3 ? 9 : NTAP) : KS;
+#ifdef MI355_EXPERIMENT_NO_MMA
+    if (a.nchunks > 100000)
+#endif
 #pragma unroll
     for (int g0 = 0; g0 < NTAP; g0 += PG) {
       Frag<T> b[PG][CT];
@@ -151,7 +165,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a) {
     to.hleft[vt] = a.ho - gh;           // rows with index < hleft are inside
     to.wleft[vt] = a.wo - gw;
   }
-  conv_epilogue_tile<T, VT, CT, TW>(a, acc, to, co_base, tile, reinterpret_cast<float*>(smem));
+  conv_epilogue_tile<T, VT, CT, TW, NW>(a, acc, to, co_base, tile, reinterpret_cast<float*>(smem));
 }
 
 template <typename T, int KS, int TD, int TH, int TW>
