@@ -121,8 +121,12 @@ typedef struct mi355_conv_desc {
   int32_t os; int32_t ooff[3];
   float* stats_part;              /* NULL or [mi355_conv_num_tiles()][2][coutp] */
   int32_t dtype;
+  /* scratch for the split-K path (few output positions, long contraction: the low U-Net / PatchGAN
+   * levels): mi355_conv_workspace_bytes() bytes of f32, may be NULL when that returns 0 */
+  void* workspace; int64_t workspace_bytes;
 } mi355_conv_desc;
 int mi355_conv_fwd(const mi355_conv_desc* d, void* stream);
+int64_t mi355_conv_workspace_bytes(const mi355_conv_desc* d);
 /* which kernel instance mi355_conv_fwd() will launch for this descriptor (for profiling tools):
  * 10000*ks + 1000*halo + 100*tile_shape + 10*voxel_subtiles_per_wave + cout_subtiles_per_wave, <0 on error */
 int mi355_conv_plan_id(const mi355_conv_desc* d);

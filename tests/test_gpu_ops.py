@@ -73,6 +73,8 @@ CONV_CASES = [
     ("k3_tiny", 1, (32,), 96, (2, 2, 2), 3, 1, 1),
     ("k3_concat", 1, (32, 64), 32, (4, 4, 32), 3, 1, 1),
     ("k3_cin24", 1, (24,), 32, (4, 4, 32), 3, 1, 1),
+    ("k3_splitk", 2, (256,), 64, (4, 8, 8), 3, 1, 1),            # few positions, long contraction: split-K path
+    ("k3_splitk_concat", 1, (128, 128), 96, (8, 8, 16), 3, 1, 1),
     ("k4s2", 1, (30,), 32, (8, 8, 16), 4, 2, 1),
     ("k4s2_ct2", 2, (32,), 64, (8, 8, 8), 4, 2, 1),
     ("k1_head", 2, (24,), 24, (4, 4, 8), 1, 1, 0),
@@ -329,7 +331,8 @@ def test_s2d_layout_definition(hip, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("n,cin,cout,sp", [(1, 30, 32, (8, 8, 32)), (2, 32, 64, (8, 8, 8)), (1, 64, 128, (4, 4, 4))])
+@pytest.mark.parametrize("n,cin,cout,sp", [(1, 30, 32, (8, 8, 32)), (2, 32, 64, (8, 8, 8)), (1, 64, 128, (4, 4, 4)),
+                                             (2, 256, 32, (4, 4, 4))])      # dS has 2048 channels: split-K, 2 channel blocks
 def test_k4s2_conv_as_dense_k2_on_s2d(hip, dtype, n, cin, cout, sp):
     from unet_bssfp_amd import functional as Fn
     g = torch.Generator().manual_seed(17)

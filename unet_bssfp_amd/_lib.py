@@ -29,7 +29,8 @@ class ConvDesc(C.Structure):
                 ("do_", _i32), ("ho", _i32), ("wo", _i32), ("ks", _i32), ("stride", _i32),
                 ("pad", _i32 * 3), ("wp", _vp), ("coutp", _i32), ("bias", _vp),
                 ("y", _vp), ("ldy", _i32), ("cstore", _i32), ("dy", _i32), ("hy", _i32), ("wy", _i32),
-                ("os", _i32), ("ooff", _i32 * 3), ("stats_part", _vp), ("dtype", _i32)]
+                ("os", _i32), ("ooff", _i32 * 3), ("stats_part", _vp), ("dtype", _i32),
+                ("workspace", _vp), ("workspace_bytes", _i64)]
 
 
 class WgradDesc(C.Structure):
@@ -62,6 +63,7 @@ _SIGNATURES = {
     "mi355_unpack_ncdhw_s2d": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mi355_weight_pack": (C.c_int, [C.POINTER(WpackDesc), _vp]),
     "mi355_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), _vp]),
+    "mi355_conv_workspace_bytes": (_i64, [C.POINTER(ConvDesc)]),
     "mi355_conv_plan_id": (C.c_int, [C.POINTER(ConvDesc)]),
     "mi355_conv_num_tiles": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(_i32), C.POINTER(_i32)]),
     "mi355_conv_wgrad_workspace": (_i64, [C.POINTER(WgradDesc)]),

@@ -10,7 +10,12 @@ struct Plan {
   int tiles_d, tiles_h, tiles_w;
   long long tiles;
   int tiles_per_sample;
+  int ksplit, rpb;            // split-K factor (1 = off) and rows per reduce block
+  long long stat_rows;        // rows of stats_part ( = tiles, or reduce blocks under split-K )
+  int stat_rows_per_sample;
 };
+
+int gcd_i(long long a, long long b) { while (b) { long long t = a % b; a = b; b = t; } return (int)a; }
 
 // 0 wide (2x4x32, 2 subtiles/wave)  1 mid (2x8x16, 2)  2 small (4x8x8, 2)
 // 3 wide4 (4x4x32, 4: bf16 thin-Cout layers)  4 mid1 (2x4x16, 1)  5 small1 (2x8x8, 1): more workgroups at the low levels
@@ -65,6 +70,31 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
     p->shape = 0;
   }
   MI355_REQUIRE(p->tiles < (1ll << 31), "conv: too many tiles");
+  p->ksplit = 1; p->rpb = 0;
+  p->stat_rows = p->tiles; p->stat_rows_per_sample = p->tiles_per_sample;
+  if (p->halo) {
+    // few output positions and a long contraction (8^3 / 16^3 U-Net levels, low PatchGAN levels): the
+    // grid cannot fill 256 CUs and every workgroup streams its weights at one L2/HBM latency per tap
+    // group => split the contraction over blockIdx.z and combine in a second kernel
+    const long long wgs = p->tiles * (d->coutp / (32 * p->ct));
+    const int nchunks = (d->c0 + d->c1) / 16;
+    if (wgs < 512 && nchunks >= 8) {
+      long long ks = (1024 + wgs - 1) / wgs;
+      if (ks > nchunks / 2) ks = nchunks / 2;
+      if (ks > 32) ks = 32;
+      if (ks >= 2) {
+        p->ksplit = (int)ks;
+        const long long per = (long long)d->do_ * d->ho * d->wo;
+        // rows per reduce block: divides the per-sample position count (statistics groups) and leaves >= ~512 blocks
+        const long long cblocks = (d->coutp + 1023) / 1024;
+        int rpb = 64;
+        while (rpb > 1 && (per % rpb != 0 || (per / rpb) * d->n * cblocks < 512)) rpb >>= 1;
+        p->rpb = gcd_i(per, rpb);
+        p->stat_rows_per_sample = (int)(per / p->rpb);
+        p->stat_rows = (long long)p->stat_rows_per_sample * d->n;
+      }
+    }
+  }
   return MI355_OK;
 }
 
@@ -85,7 +115,14 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
   a.tiles_d = p.tiles_d; a.tiles_h = p.tiles_h; a.tiles_w = p.tiles_w;
   a.nchunks = (d->c0 + d->c1) / 16;
   a.m_total = (long long)d->n * d->do_ * d->ho * d->wo;
-  dim3 grid((unsigned)p.tiles, (unsigned)(d->coutp / (32 * p.ct)));
+  a.ksplit = p.ksplit;
+  a.kslab = (float*)d->workspace;
+  if (p.ksplit > 1) {
+    const long long need = (long long)p.ksplit * a.m_total * d->coutp * 4;
+    MI355_REQUIRE(d->workspace && d->workspace_bytes >= need, "conv: split-K workspace too small (%lld < %lld)",
+                  (long long)d->workspace_bytes, need);
+  }
+  dim3 grid((unsigned)p.tiles, (unsigned)(d->coutp / (32 * p.ct)), (unsigned)p.ksplit);
   dim3 block(p.halo && p.shape == 6 ? 512 : 256);
 #define HALO(KS, TD, TH, TW, CT)                                     \
   do {                                                               \
@@ -128,6 +165,12 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
   }
 #undef HALO
 #undef HALO_KS
+  if (p.ksplit > 1) {
+    int rc = mi355_check_launch("conv_fwd");
+    if (rc) return rc;
+    conv_ksplit_reduce_kernel<T><<<dim3((unsigned)p.stat_rows, (unsigned)((d->coutp + 1023) / 1024)), dim3(256), 0, st>>>(a, p.rpb);
+    return mi355_check_launch("conv_ksplit_reduce");
+  }
   return mi355_check_launch("conv_fwd");
 }
 
@@ -144,9 +187,16 @@ extern "C" int mi355_conv_num_tiles(const mi355_conv_desc* d, int32_t* tiles, in
   Plan p;
   int rc = make_plan(d, &p);
   if (rc) return rc;
-  if (tiles) *tiles = (int32_t)p.tiles;
-  if (tiles_per_sample) *tiles_per_sample = p.tiles_per_sample;
+  if (tiles) *tiles = (int32_t)p.stat_rows;
+  if (tiles_per_sample) *tiles_per_sample = p.stat_rows_per_sample;
   return MI355_OK;
+}
+
+extern "C" int64_t mi355_conv_workspace_bytes(const mi355_conv_desc* d) {
+  Plan p;
+  if (make_plan(d, &p)) return -1;
+  if (p.ksplit <= 1) return 0;
+  return (int64_t)p.ksplit * d->n * d->do_ * d->ho * d->wo * d->coutp * 4;
 }
 
 extern "C" int mi355_conv_fwd(const mi355_conv_desc* d, void* stream) {

@@ -17,6 +17,8 @@ struct ConvArgs {
   int tiles_d, tiles_h, tiles_w;   // halo kernel
   int nchunks;
   long long m_total;               // gather kernel: n*do*ho*wo
+  int ksplit;                      // halo kernel: contraction split over blockIdx.z (1 = off)
+  float* kslab;                    // [ksplit][n*do*ho*wo][coutp] f32 partial sums
 };
 
 // Epilogue shared by both kernels.

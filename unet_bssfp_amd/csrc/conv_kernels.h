@@ -116,12 +116,16 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(const ConvArgs a) {
       for (int i = 0; i < 16; ++i) acc[vt][ct][i] = 0.f;
 
   plan_tile(tile);
-  load_chunk(0);
-  for (int c = 0; c < a.nchunks; ++c) {
+  // split-K: this workgroup contracts the chunk range [c_begin, c_end) only
+  const int cps = (a.nchunks + a.ksplit - 1) / a.ksplit;
+  const int c_begin = blockIdx.z * cps;
+  const int c_end = min(a.nchunks, c_begin + cps);
+  if (c_begin < c_end) load_chunk(c_begin);
+  for (int c = c_begin; c < c_end; ++c) {
     __syncthreads();                 // previous chunk's LDS reads are done
     store_chunk();
     __syncthreads();
-    if (c + 1 < a.nchunks) load_chunk(c + 1);   // in flight under the MFMAs
+    if (c + 1 < c_end) load_chunk(c + 1);       // in flight under the MFMAs
     const char* wc = wlane + (long long)c * NTAP * wtap;
     // weight fragments are fetched PG taps at a time (all loads of a group in flight together);
     // the group size was measured irrelevant (3 / 9 / 27): the L2-resident weights are not the limiter
@@ -165,7 +169,91 @@ __global__ __launch_bounds__(NW * 64) void conv_halo_kernel(const ConvArgs a) {
     to.hleft[vt] = a.ho - gh;           // rows with index < hleft are inside
     to.wleft[vt] = a.wo - gw;
   }
+  if (a.ksplit > 1) {
+    // partial sums go to the f32 slab of this split; bias, statistics and the store in T happen in
+    // conv_ksplit_reduce_kernel (fixed summation order => deterministic)
+    ConvArgs s2 = a;
+    s2.y = reinterpret_cast<char*>(a.kslab + (long long)blockIdx.z * a.m_total * a.coutp);
+    s2.ldy = a.coutp; s2.cstore = a.coutp; s2.bias = nullptr; s2.stats = nullptr;
+    to.hstride = (long long)a.wo * a.coutp;
+    to.wstride = a.coutp;
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt) {
+      const int s = wave * VT + vt;
+      const int gd = d0 + s / SPD, gh = h0 + (s % SPD) * RS, gw = w0;
+      to.base[vt] = ((((long long)tn * a.do_ + gd) * a.ho + gh) * a.wo + gw) * a.coutp;
+    }
+    conv_epilogue_tile<float, VT, CT, TW, NW>(s2, acc, to, co_base, tile, reinterpret_cast<float*>(smem));
+    return;
+  }
   conv_epilogue_tile<T, VT, CT, TW, NW>(a, acc, to, co_base, tile, reinterpret_cast<float*>(smem));
+}
+
+// Combine the split-K slabs: z = sum_k slab[k] + bias, store in T at the (possibly scattered) output
+// position, and emit the per-block channel statistics of (z - bias).  One block = rpb positions.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_ksplit_reduce_kernel(const ConvArgs a, int rpb) {
+  __shared__ float red[256 * 8];
+  const int cblk = blockIdx.y * 1024;          // channel block of this workgroup (<= 1024 channels)
+  const int cw = min(1024, a.coutp - cblk);
+  const int lpr = cw / 4;                      // float4 pieces per position (<= 256)
+  const int rpp = 256 / lpr;
+  const int piece = threadIdx.x % lpr, rsub = threadIdx.x / lpr;
+  const int ch0 = cblk + piece * 4;
+  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+  float bias[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bias[j] = (a.bias && ch0 + j < a.cstore) ? a.bias[ch0 + j] : 0.f;
+  const long long r0 = (long long)blockIdx.x * rpb;
+  if (rsub < rpp)
+    for (long long row = r0 + rsub; row < r0 + rpb && row < a.m_total; row += rpp) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float* sp = a.kslab + row * a.coutp + ch0;
+      const long long ss = a.m_total * a.coutp;
+      int k = 0;
+      for (; k + 4 <= a.ksplit; k += 4) {          // 4 independent loads in flight, fixed summation order
+        const float4 p0 = *reinterpret_cast<const float4*>(sp + (long long)k * ss);
+        const float4 p1 = *reinterpret_cast<const float4*>(sp + (long long)(k + 1) * ss);
+        const float4 p2 = *reinterpret_cast<const float4*>(sp + (long long)(k + 2) * ss);
+        const float4 p3 = *reinterpret_cast<const float4*>(sp + (long long)(k + 3) * ss);
+        v.x += (p0.x + p1.x) + (p2.x + p3.x); v.y += (p0.y + p1.y) + (p2.y + p3.y);
+        v.z += (p0.z + p1.z) + (p2.z + p3.z); v.w += (p0.w + p1.w) + (p2.w + p3.w);
+      }
+      for (; k < a.ksplit; ++k) {
+        const float4 p = *reinterpret_cast<const float4*>(sp + (long long)k * ss);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+      }
+      const float f[4] = {v.x, v.y, v.z, v.w};
+      long long t = row;
+      const int gw = (int)(t % a.wo); t /= a.wo;
+      const int gh = (int)(t % a.ho); t /= a.ho;
+      const int gd = (int)(t % a.do_); const long long n = t / a.do_;
+      T* yp = reinterpret_cast<T*>(a.y) + (((n * a.dy + (gd * a.os + a.od)) * a.hy + (gh * a.os + a.oh)) * a.wy + (gw * a.os + a.ow)) * a.ldy;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s0[j] += f[j];
+        s1[j] += f[j] * f[j];
+        if (ch0 + j < a.cstore) Elem<T>::store(yp + ch0 + j, f[j] + bias[j]);
+      }
+    }
+  if (!a.stats) return;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    red[threadIdx.x * 8 + j] = s0[j];
+    red[threadIdx.x * 8 + 4 + j] = s1[j];
+  }
+  __syncthreads();
+  for (int cl = threadIdx.x; cl < cw; cl += 256) {
+    const int p = cl / 4, j = cl % 4;
+    float t0 = 0.f, t1 = 0.f;
+    for (int qq = 0; qq < rpp; ++qq) {
+      t0 += red[(qq * lpr + p) * 8 + j];
+      t1 += red[(qq * lpr + p) * 8 + 4 + j];
+    }
+    float* out = a.stats + (long long)blockIdx.x * 2 * a.coutp;
+    out[cblk + cl] = t0;
+    out[a.coutp + cblk + cl] = t1;
+  }
 }
 
 template <typename T, int KS, int TD, int TH, int TW>

@@ -190,6 +190,13 @@ def conv_fwd(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os=1, ooff=(0,
     assert bias is None or (bias.dtype == torch.float32 and bias.numel() >= coutp)
     d = _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, stats)
     lib = _lib.load()
+    need = lib.mi355_conv_workspace_bytes(C.byref(d))
+    if need < 0:
+        _lib.check(-1, "conv_workspace_bytes")
+    ws = None
+    if need > 0:                                     # split-K partial sums (low levels)
+        ws = torch.empty((need // 4,), dtype=torch.float32, device=x0.device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), need
     after = CONV_PROBE(lib.mi355_conv_plan_id(C.byref(d)), d, real) if CONV_PROBE is not None else None
     _lib.check(lib.mi355_conv_fwd(C.byref(d), _stream()), "conv_fwd")
     if after is not None:
