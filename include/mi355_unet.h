@@ -124,6 +124,10 @@ typedef struct mi355_conv_desc {
   /* scratch for the split-K path (few output positions, long contraction: the low U-Net / PatchGAN
    * levels): mi355_conv_workspace_bytes() bytes of f32, may be NULL when that returns 0 */
   void* workspace; int64_t workspace_bytes;
+  /* ConvTranspose3d(k=2, s=2) forward as ONE 1x1x1 GEMM with 8*cls_cout output columns: column
+   * blk*cls_cout + co is stored at output position 2p + (bd,bh,bw) (os must be 2), channel co.
+   * 0 = off.  Weights: mi355_weight_pack with s2d_mode 2, s2d_cp = cls_cout. */
+  int32_t cls_cout;
 } mi355_conv_desc;
 int mi355_conv_fwd(const mi355_conv_desc* d, void* stream);
 int64_t mi355_conv_workspace_bytes(const mi355_conv_desc* d);
@@ -158,6 +162,9 @@ typedef struct mi355_wgrad_desc {
   int32_t accumulate;                       /* 0: overwrite, 1: add into dw */
   int32_t dtype;
   int32_t s2d_cp;                           /* >0: x is a space-to-depth tensor, ci = blk*s2d_cp + c (cin = real c) */
+  int32_t g_cls_cout;                       /* >0: weight gradient of ConvTranspose3d(k2,s2) in one launch: GEMM column
+                                               blk*g_cls_cout + co reads g at position 2p + (bd,bh,bw), channel co, and
+                                               lands in tap (bd,bh,bw) of dw (ks must be 1, bf16 only) */
 } mi355_wgrad_desc;
 int64_t mi355_conv_wgrad_workspace(const mi355_wgrad_desc* d);
 int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream);

@@ -30,7 +30,7 @@ class ConvDesc(C.Structure):
                 ("pad", _i32 * 3), ("wp", _vp), ("coutp", _i32), ("bias", _vp),
                 ("y", _vp), ("ldy", _i32), ("cstore", _i32), ("dy", _i32), ("hy", _i32), ("wy", _i32),
                 ("os", _i32), ("ooff", _i32 * 3), ("stats_part", _vp), ("dtype", _i32),
-                ("workspace", _vp), ("workspace_bytes", _i64)]
+                ("workspace", _vp), ("workspace_bytes", _i64), ("cls_cout", _i32)]
 
 
 class WgradDesc(C.Structure):
@@ -41,7 +41,8 @@ class WgradDesc(C.Structure):
                 ("gs", _i32), ("goff", _i32 * 3), ("ks", _i32), ("stride", _i32), ("pad", _i32 * 3),
                 ("workspace", _vp), ("workspace_bytes", _i64),
                 ("dw", _vp), ("cout", _i32), ("cin", _i32), ("s_co", _i64), ("s_ci", _i64), ("s_k", _i64 * 3),
-                ("tbase", _i32 * 3), ("tstep", _i32 * 3), ("accumulate", _i32), ("dtype", _i32), ("s2d_cp", _i32)]
+                ("tbase", _i32 * 3), ("tstep", _i32 * 3), ("accumulate", _i32), ("dtype", _i32), ("s2d_cp", _i32),
+                ("g_cls_cout", _i32)]
 
 
 class NormActDesc(C.Structure):

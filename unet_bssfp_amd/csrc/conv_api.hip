@@ -34,9 +34,16 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
   MI355_REQUIRE(d->ks >= 1 && d->ks <= 4 && d->stride >= 1 && d->stride <= 2, "conv: unsupported ks=%d stride=%d", d->ks, d->stride);
   MI355_REQUIRE(d->n > 0 && d->di > 0 && d->hi > 0 && d->wi > 0 && d->do_ > 0 && d->ho > 0 && d->wo > 0, "conv: empty extent");
   MI355_REQUIRE(d->os >= 1, "conv: os < 1");
-  MI355_REQUIRE((d->do_ - 1) * d->os + d->ooff[0] < d->dy && (d->ho - 1) * d->os + d->ooff[1] < d->hy &&
-                    (d->wo - 1) * d->os + d->ooff[2] < d->wy && d->ooff[0] >= 0 && d->ooff[1] >= 0 && d->ooff[2] >= 0,
-                "conv: output grid exceeds the output tensor");
+  MI355_REQUIRE(d->cls_cout == 0 || (d->ks == 1 && d->stride == 1 && d->os == 2 && d->cls_cout % 64 == 0 &&
+                                     d->coutp == 8 * d->cls_cout && d->cstore <= d->cls_cout && !d->stats_part &&
+                                     d->ooff[0] == 0 && d->ooff[1] == 0 && d->ooff[2] == 0),
+                "conv: bad transposed-conv class folding (cls_cout=%d)", d->cls_cout);
+  {
+    const int hi_off = d->cls_cout ? 1 : 0;     // classes reach offset 1 in every dimension
+    MI355_REQUIRE((d->do_ - 1) * d->os + d->ooff[0] + hi_off < d->dy && (d->ho - 1) * d->os + d->ooff[1] + hi_off < d->hy &&
+                      (d->wo - 1) * d->os + d->ooff[2] + hi_off < d->wy && d->ooff[0] >= 0 && d->ooff[1] >= 0 && d->ooff[2] >= 0,
+                  "conv: output grid exceeds the output tensor");
+  }
   p->ct = (d->coutp % 64 == 0) ? 2 : 1;
   p->halo = ((d->ks == 3 || d->ks == 2) && d->stride == 1);
   if (p->halo) {
@@ -116,6 +123,7 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
   a.nchunks = (d->c0 + d->c1) / 16;
   a.m_total = (long long)d->n * d->do_ * d->ho * d->wo;
   a.ksplit = p.ksplit;
+  a.cls_cout = d->cls_cout;
   a.kslab = (float*)d->workspace;
   if (p.ksplit > 1) {
     const long long need = (long long)p.ksplit * a.m_total * d->coutp * 4;

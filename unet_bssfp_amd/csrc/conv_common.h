@@ -19,6 +19,7 @@ struct ConvArgs {
   long long m_total;               // gather kernel: n*do*ho*wo
   int ksplit;                      // halo kernel: contraction split over blockIdx.z (1 = off)
   float* kslab;                    // [ksplit][n*do*ho*wo][coutp] f32 partial sums
+  int cls_cout;                    // gather kernel: transposed-conv classes folded into the cout index (0 = off)
 };
 
 // Epilogue shared by both kernels.
@@ -28,7 +29,9 @@ struct ConvArgs {
 template <typename T, int VT, int CT>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[VT][CT],
                                               const long long (&yoff)[VT], int co_base,
-                                              int tile_index, float* red /* LDS, >= 4*CT*64 floats */) {
+                                              int tile_index, float* red /* LDS, >= 4*CT*64 floats */,
+                                              int co_store_base = -1) {
+  if (co_store_base < 0) co_store_base = co_base;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   float s1[CT], s2[CT];
@@ -46,7 +49,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[V
       if (off >= 0) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-          const int co = co_base + ct * 32 + r;
+          const int co = co_store_base + ct * 32 + r;
           const float v = acc[vt][ct][i];
           s1[ct] += v;
           s2[ct] += v * v;

@@ -329,12 +329,19 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvArgs a) {
     if (++kw == a.ks) { kw = 0; if (++kh == a.ks) { kh = 0; ++kd; } }
   }
 
+  // transposed-conv classes folded into the cout index: this workgroup's 32*CT columns belong to ONE class
+  int od = a.od, oh = a.oh, ow = a.ow, co_store = co_base;
+  if (a.cls_cout) {
+    const int cls = co_base / a.cls_cout;
+    co_store = co_base - cls * a.cls_cout;
+    od = cls >> 2; oh = (cls >> 1) & 1; ow = cls & 1;
+  }
   long long yoff[VT];
 #pragma unroll
   for (int vt = 0; vt < VT; ++vt) {
-    yoff[vt] = vok[vt] ? ((((long long)vn[vt] * a.dy + (vd[vt] * a.os + a.od)) * a.hy +
-                           (vh[vt] * a.os + a.oh)) * a.wy + (vw[vt] * a.os + a.ow)) * a.ldy
+    yoff[vt] = vok[vt] ? ((((long long)vn[vt] * a.dy + (vd[vt] * a.os + od)) * a.hy +
+                           (vh[vt] * a.os + oh)) * a.wy + (vw[vt] * a.os + ow)) * a.ldy
                        : -1;
   }
-  conv_epilogue<T, VT, CT>(a, acc, yoff, co_base, blockIdx.x, red);
+  conv_epilogue<T, VT, CT>(a, acc, yoff, co_base, blockIdx.x, red, co_store);
 }

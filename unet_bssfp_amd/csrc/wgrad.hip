@@ -25,6 +25,7 @@ struct WgradArgs {
   int splits;
   int tap_groups;
   long long rows;        // n*do*ho
+  int g_cls_cout;        // fast kernel, KS=1: GEMM column blk*g_cls_cout + co reads g at 2p + bits(blk)
 };
 
 template <typename T> __device__ __forceinline__ float ld1(const char* p, long long idx) {
@@ -109,6 +110,7 @@ struct WreduceArgs {
   int tb0, tb1, tb2, ts0, ts1, ts2;
   int accumulate;
   int s2d_cp;
+  int co_cls;            // >0: co index is blk*co_cls + co, blk selects the destination tap
 };
 
 // 256 threads = 32 consecutive elements x 8 slab lanes; fixed-order LDS combine (deterministic)
@@ -132,11 +134,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WreduceArgs a) 
   if (sl != 0 || idx >= per) return;
 #pragma unroll
   for (int q = 1; q < 8; ++q) s += red[q][e];
-  const int co = (int)(idx % a.coutp);
+  int co = (int)(idx % a.coutp);
   int ci = (int)((idx / a.coutp) % a.cinp);
   const int tap = (int)(idx / ((long long)a.coutp * a.cinp));
   int blk = 0;
   if (a.s2d_cp) { blk = ci / a.s2d_cp; ci = ci % a.s2d_cp; }
+  if (a.co_cls) { blk = co / a.co_cls; co = co % a.co_cls; }
   if (co >= a.cout || ci >= a.cin || blk >= 8) return;
   const int td = tap / (a.ks * a.ks), th = (tap / a.ks) % a.ks, tw = tap % a.ks;
   const long long dst = co * a.s_co + ci * a.s_ci + (a.tb0 + a.ts0 * td + (blk >> 2)) * a.s_k0 +
@@ -187,12 +190,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradArgs a, i
   const long long ldx = first ? a.ld0 : a.ld1;
   const int cix = first ? ci_base : ci_base - a.c0;
   const int cx_lim = (first ? a.c0 : a.c1) - cix;      // channels of this source left from cix
-  const int cg_lim = a.cg - co_base;
+  // transposed-conv classes folded into the column index: this workgroup's 32 columns are one class
+  int gs = 1, gbd = 0, gbh = 0, gbw = 0, gco = co_base;
+  if (a.g_cls_cout) {
+    const int cls = co_base / a.g_cls_cout;
+    gco = co_base - cls * a.g_cls_cout;
+    gs = 2; gbd = cls >> 2; gbh = (cls >> 1) & 1; gbw = cls & 1;
+  }
+  const int cg_lim = (a.g_cls_cout ? a.g_cls_cout : a.cg) - gco;
+  constexpr bool WSPLIT = (KS == 1);                    // one tap: the 4 waves split the k-groups instead
 
   int toff[TPWV];
 #pragma unroll
   for (int i = 0; i < TPWV; ++i) {
-    const int tap = wave + 4 * i;
+    const int tap = WSPLIT ? 0 : wave + 4 * i;
     const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
     toff[i] = tap < NT ? ((kd * HH + kh) * HW + kw) * 64 : 0;
   }
@@ -236,13 +247,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradArgs a, i
       const int sw = row % TW, sh = (row / TW) % TH, sd = row / (TW * TH);
       const int gd = d0 + sd, gh = h0 + sh, gw = w0 + sw;
       const bool ok = p < GROWS * 4 && part * 8 < cg_lim && gd < a.do_ && gh < a.ho && gw < a.wo;
-      const uint4 v = ok ? *reinterpret_cast<const uint4*>(a.g + (((((long long)n * a.gd + gd) * a.gh + gh) * a.gw + gw) * (long long)a.ldg + co_base + part * 8) * 2)
+      const uint4 v = ok ? *reinterpret_cast<const uint4*>(a.g + (((((long long)n * a.gd + (gd * gs + gbd)) * a.gh + (gh * gs + gbh)) * a.gw + (gw * gs + gbw)) * (long long)a.ldg + gco + part * 8) * 2)
                          : make_uint4(0, 0, 0, 0);
       if (p < GROWS * 4) *reinterpret_cast<uint4*>(gsm + p * 16) = v;
     }
     __syncthreads();
 #pragma unroll 2
-    for (int kg = 0; kg < TD * TH * SEGS; ++kg) {
+    for (int kg = WSPLIT ? wave : 0; kg < TD * TH * SEGS; kg += WSPLIT ? 4 : 1) {
       const int seg = kg % SEGS, sh = (kg / SEGS) % TH, sd = kg / (SEGS * TH);
       const char* gp = gsm + ((sd * TH + sh) * TW + seg * 16) * 64 + lane_off;
       const char* xp = xs + ((sd * HH + sh) * HW + seg * 16) * 64 + lane_off;
@@ -254,11 +265,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradArgs a, i
       }
     }
   }
-  float* sl = a.slab + ((long long)blockIdx.x * NT) * a.cinp * a.coutp;
+  float* sl = a.slab + ((long long)(WSPLIT ? blockIdx.x * 4 + wave : blockIdx.x) * NT) * a.cinp * a.coutp;
   const int co = co_base + r;
 #pragma unroll
   for (int i = 0; i < TPWV; ++i) {
-    const int tap = wave + 4 * i;
+    const int tap = WSPLIT ? 0 : wave + 4 * i;
     if (tap < NT) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
@@ -288,7 +299,7 @@ int wplan(const mi355_wgrad_desc* d, WPlan* p) {
   const int nt = d->ks * d->ks * d->ks;
   p->tap_groups = (nt + p->tpw - 1) / p->tpw;
   p->cinp32 = ((d->c0 + d->c1 + 31) / 32) * 32;
-  p->coutp32 = ((d->cg + 31) / 32) * 32;
+  p->coutp32 = d->g_cls_cout > 0 ? 8 * d->g_cls_cout : ((d->cg + 31) / 32) * 32;
   p->ci_tiles = p->cinp32 / 32;
   p->co_tiles = p->coutp32 / 32;
   p->rows = (long long)d->n * d->do_ * d->ho;
@@ -303,21 +314,27 @@ int wplan(const mi355_wgrad_desc* d, WPlan* p) {
   p->splits = (int)s;
   p->nslabs = p->splits * 4;
   // fast path: bf16, 3x3x3 stride 1, g on the same grid as the outputs
-  p->fast = d->dtype == MI355_DT_BF16 && (d->ks == 3 || d->ks == 2) && d->stride == 1 && d->gs == 1 && d->goff[0] == 0 &&
-            d->goff[1] == 0 && d->goff[2] == 0 && d->gd == d->do_ && d->gh == d->ho && d->gw == d->wo &&
-            d->ld0 % 8 == 0 && (d->c1 == 0 || d->ld1 % 8 == 0) && d->ldg % 8 == 0;
+  const bool cls = d->g_cls_cout > 0;
+  MI355_REQUIRE(!cls || (d->dtype == MI355_DT_BF16 && d->ks == 1 && d->stride == 1 && d->g_cls_cout % 32 == 0 &&
+                         d->cg >= d->g_cls_cout && d->gd == 2 * d->do_ && d->gh == 2 * d->ho && d->gw == 2 * d->wo &&
+                         d->c1 == 0 && d->cout <= d->g_cls_cout),
+                "wgrad: bad transposed-conv class folding");
+  p->fast = d->dtype == MI355_DT_BF16 && d->stride == 1 && d->ld0 % 8 == 0 && (d->c1 == 0 || d->ld1 % 8 == 0) && d->ldg % 8 == 0 &&
+            (cls || ((d->ks == 3 || d->ks == 2) && d->gs == 1 && d->goff[0] == 0 && d->goff[1] == 0 && d->goff[2] == 0 &&
+                     d->gd == d->do_ && d->gh == d->ho && d->gw == d->wo));
   if (p->fast) {
     p->shape = d->wo > 16 ? 0 : 1;
     p->tiles_d = ceil_div(d->do_, kWTD[p->shape]);
     p->tiles_h = ceil_div(d->ho, kWTH[p->shape]);
     p->tiles_w = ceil_div(d->wo, kWTW[p->shape]);
     p->ntiles = p->tiles_d * p->tiles_h * p->tiles_w * d->n;
-    long long sp = 512 / ((long long)p->ci_tiles * p->co_tiles);
+    const int wsl = d->ks == 1 ? 4 : 1;                     // slabs per workgroup
+    long long sp = 256 / ((long long)p->ci_tiles * p->co_tiles);
     if (sp < 1) sp = 1;
     if (sp > p->ntiles) sp = p->ntiles;
-    while (sp > 1 && sp * slab_bytes > (256ll << 20)) sp /= 2;
+    while (sp > 1 && sp * wsl * slab_bytes > (256ll << 20)) sp /= 2;
     p->splits = (int)sp;
-    p->nslabs = p->splits;
+    p->nslabs = d->ks == 1 ? p->splits * 4 : p->splits;
   }
   return MI355_OK;
 }
@@ -362,6 +379,7 @@ extern "C" int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream) {
   a.stride = d->stride; a.pd = d->pad[0]; a.ph = d->pad[1]; a.pw = d->pad[2];
   a.slab = d->workspace; a.cinp = p.cinp32; a.coutp = p.coutp32;
   a.splits = p.splits; a.tap_groups = p.tap_groups; a.rows = p.rows;
+  a.g_cls_cout = d->g_cls_cout;
   if (p.fast) {
     dim3 grid(p.splits, p.ci_tiles, p.co_tiles), block(256);
 #define WG_FAST(KS, TD, TH, TW)                                                                   \
@@ -370,7 +388,8 @@ extern "C" int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream) {
     wgrad_bf16_kernel<KS, TD, TH, TW><<<grid, block, lds, st>>>(a, p.tiles_d, p.tiles_h, p.tiles_w, p.ntiles); \
   } while (0)
     if (d->ks == 3) { if (p.shape == 0) WG_FAST(3, 2, 4, 32); else WG_FAST(3, 2, 8, 16); }
-    else { if (p.shape == 0) WG_FAST(2, 2, 4, 32); else WG_FAST(2, 2, 8, 16); }
+    else if (d->ks == 2) { if (p.shape == 0) WG_FAST(2, 2, 4, 32); else WG_FAST(2, 2, 8, 16); }
+    else { if (p.shape == 0) WG_FAST(1, 2, 4, 32); else WG_FAST(1, 2, 8, 16); }
 #undef WG_FAST
   } else if (d->dtype == MI355_DT_F32) launch_wgrad<float>(a, p, st);
   else launch_wgrad<bf16_t>(a, p, st);
@@ -385,6 +404,7 @@ extern "C" int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream) {
   q.ts0 = d->tstep[0]; q.ts1 = d->tstep[1]; q.ts2 = d->tstep[2];
   q.accumulate = d->accumulate;
   q.s2d_cp = d->s2d_cp;
+  q.co_cls = d->g_cls_cout;
   const long long per = (long long)q.ntaps * q.cinp * q.coutp;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 31) / 32)), dim3(256), 0, st, q);
   return mi355_check_launch("wgrad_reduce");

@@ -168,6 +168,12 @@ class ConvSpec:
         return self.cache.get(("dfwd", dtype, cinp, cls), w, lambda r: ops.weight_pack(
             w.detach(), self.cout, self.cin, 1, 8, self.cout * 8, (4, 2, 1), cls, (0, 0, 0), dtype, cinp, reuse=r))
 
+    def w_deconv_fwd_all(self, w, dtype, cinp):
+        # all 8 parity classes as ONE GEMM: column blk*Cout + co  <-  w[ci][co][(bd,bh,bw)]
+        return self.cache.get(("dfwd_all", dtype, cinp), w, lambda r: ops.weight_pack(
+            w.detach(), self.cout, self.cin, 1, 8, self.cout * 8, (4, 2, 1), (0, 0, 0), (0, 0, 0), dtype, cinp,
+            coutp=8 * self.cout, s2d_mode=2, s2d_cp=self.cout, reuse=r))
+
     def w_deconv_dgrad(self, w, dtype, cinp):
         return self.cache.get(("ddgrad", dtype, cinp), w, lambda r: ops.weight_pack(
             w.detach(), self.cin, self.cout, 2, self.cout * 8, 8, (4, 2, 1), (0, 0, 0), (1, 1, 1), dtype, cinp, reuse=r))
@@ -233,11 +239,17 @@ class ConvFn(Function):
                          real=(spec.cin, spec.cout))
         else:
             assert x1 is None and not want_stats
-            for cls in CLASSES8:
-                wp, coutp, _ = spec.w_deconv_fwd(weight, dtype, c0, cls)
-                bp = _padded(bias, coutp)
-                ops.conv_fwd(x0, None, wp, coutp, bp, 1, 1, (0, 0, 0), out, (di, hi, wi), os=2, ooff=cls,
-                             real=(spec.cin, spec.cout))
+            if spec.cout % 64 == 0:
+                # the 8 parity classes folded into the column index of one 1x1x1 GEMM (8*Cout columns)
+                wp, coutp, _ = spec.w_deconv_fwd_all(weight, dtype, c0)
+                ops.conv_fwd(x0, None, wp, coutp, _padded(bias, spec.cout), 1, 1, (0, 0, 0), out, (di, hi, wi), os=2,
+                             real=(spec.cin, 8 * spec.cout), cls_cout=spec.cout)
+            else:
+                for cls in CLASSES8:
+                    wp, coutp, _ = spec.w_deconv_fwd(weight, dtype, c0, cls)
+                    bp = _padded(bias, coutp)
+                    ops.conv_fwd(x0, None, wp, coutp, bp, 1, 1, (0, 0, 0), out, (di, hi, wi), os=2, ooff=cls,
+                                 real=(spec.cin, spec.cout))
         ctx.save_for_backward(x0, x1, weight)
         ctx.spec = spec
         ctx.has_bias = bias is not None
@@ -293,6 +305,11 @@ class ConvFn(Function):
             elif spec.kind == "conv":
                 ops.conv_wgrad(x0, x1, dz, (do_, ho, wo), 1, (0, 0, 0), k, spec.stride, (spec.pad,) * 3, dw,
                                spec.cout, spec.cin, spec.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (1, 1, 1))
+            elif dtype == torch.bfloat16 and spec.cout % 32 == 0 and cg == spec.cout:
+                # transposed conv: the 8 classes are 8*Cout GEMM columns of one k=1 weight-gradient launch
+                ops.conv_wgrad(x0, None, dz, (di, hi, wi), 1, (0, 0, 0), 1, 1, (0, 0, 0), dw,
+                               spec.cout, spec.cin, 8, spec.cout * 8, (4, 2, 1), (0, 0, 0), (0, 0, 0),
+                               g_cls_cout=spec.cout)
             else:
                 for cls in CLASSES8:
                     ops.conv_wgrad(x0, None, dz, (di, hi, wi), 2, cls, 1, 1, (0, 0, 0), dw,

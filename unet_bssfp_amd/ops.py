@@ -148,7 +148,7 @@ def weight_pack(src: torch.Tensor, cout: int, cin: int, ks: int, s_co: int, s_ci
 
 
 # ------------------------------------------------------------------------------ convolution
-def _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, stats):
+def _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, stats, cls_cout=0):
     d = _lib.ConvDesc()
     n, di, hi, wi, c0 = x0.shape
     d.x0, d.c0, d.ld0 = x0.data_ptr(), c0, act_ld(x0)
@@ -169,6 +169,7 @@ def _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, st
     d.ooff = (C.c_int32 * 3)(*ooff)
     d.stats_part = _ptr(stats)
     d.dtype = _DT[x0.dtype]
+    d.cls_cout = cls_cout
     return d
 
 
@@ -184,11 +185,12 @@ def conv_num_tiles(x0, x1, wp, coutp, ks, stride, pad, out, grid, os=1, ooff=(0,
 CONV_PROBE = None
 
 
-def conv_fwd(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os=1, ooff=(0, 0, 0), stats=None, real=None):
+def conv_fwd(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os=1, ooff=(0, 0, 0), stats=None, real=None,
+             cls_cout=0):
     require_cuda(x0, x1, wp, bias, out, stats)
     assert out.dtype == x0.dtype and wp.dtype == x0.dtype
-    assert bias is None or (bias.dtype == torch.float32 and bias.numel() >= coutp)
-    d = _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, stats)
+    assert bias is None or (bias.dtype == torch.float32 and bias.numel() >= (cls_cout or coutp))
+    d = _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, stats, cls_cout)
     lib = _lib.load()
     need = lib.mi355_conv_workspace_bytes(C.byref(d))
     if need < 0:
@@ -204,7 +206,7 @@ def conv_fwd(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os=1, ooff=(0,
 
 
 def conv_wgrad(x0, x1, g, grid, gs, goff, ks, stride, pad, dw, cout, cin, s_co, s_ci, s_k, tbase, tstep,
-               accumulate=False, s2d_cp=0):
+               accumulate=False, s2d_cp=0, g_cls_cout=0):
     """dw (torch layout, f32) (+)= sum_p x[p*stride+tap-pad] * g[p*gs+goff]."""
     require_cuda(x0, x1, g, dw)
     assert dw.dtype == torch.float32 and g.dtype == x0.dtype
@@ -231,6 +233,7 @@ def conv_wgrad(x0, x1, g, grid, gs, goff, ks, stride, pad, dw, cout, cin, s_co, 
     d.accumulate = 1 if accumulate else 0
     d.dtype = _DT[x0.dtype]
     d.s2d_cp = s2d_cp
+    d.g_cls_cout = g_cls_cout
     lib = _lib.load()
     need = lib.mi355_conv_wgrad_workspace(C.byref(d))
     if need < 0:
