@@ -329,7 +329,7 @@ int wplan(const mi355_wgrad_desc* d, WPlan* p) {
     p->tiles_w = ceil_div(d->wo, kWTW[p->shape]);
     p->ntiles = p->tiles_d * p->tiles_h * p->tiles_w * d->n;
     const int wsl = d->ks == 1 ? 4 : 1;                     // slabs per workgroup
-    long long sp = 256 / ((long long)p->ci_tiles * p->co_tiles);
+    long long sp = 512 / ((long long)p->ci_tiles * p->co_tiles);      // ~2 workgroups per CU (256 measured slower)
     if (sp < 1) sp = 1;
     if (sp > p->ntiles) sp = p->ntiles;
     while (sp > 1 && sp * wsl * slab_bytes > (256ll << 20)) sp /= 2;
