@@ -216,14 +216,12 @@ __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __re
 __device__ __forceinline__ unsigned long long eff_seed(unsigned long long salt, const unsigned long long* p) {
   return p ? p[0] * 0x9E3779B97F4A7C15ull + salt * 0xD1B54A32D192ED03ull + 1ull : salt;
 }
-// keep-mask of element `idx` (logical index, independent of ld): 16 bits of a 32-bit mix
+// keep-mask of element `idx` (logical index, independent of ld): 16 bits per element, one 64-bit mix per
+// aligned group of 4 elements (the compiler shares it across the 4 / 8 elements of a 16-byte piece)
 __device__ __forceinline__ bool drop_keep(unsigned long long seed, unsigned long long idx, unsigned thr16) {
-  const unsigned long long pair = idx >> 1;
-  unsigned x = (unsigned)pair ^ (unsigned)(pair >> 32) * 0x9E3779B9u ^ (unsigned)seed;
-  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-  x += (unsigned)(seed >> 32);
-  x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12;
-  const unsigned bits = (idx & 1) ? (x >> 16) : (x & 0xffffu);
+  unsigned long long x = (idx >> 2) * 0x9E3779B97F4A7C15ull + seed;
+  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull; x ^= x >> 32;
+  const unsigned bits = (unsigned)(x >> (16 * (idx & 3))) & 0xffffu;
   return bits >= thr16;
 }
 

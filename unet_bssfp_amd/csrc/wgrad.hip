@@ -113,38 +113,54 @@ struct WreduceArgs {
   int co_cls;            // >0: co index is blk*co_cls + co, blk selects the destination tap
 };
 
-// 256 threads = 32 consecutive elements x 8 slab lanes; fixed-order LDS combine (deterministic)
+// 256 threads = 32 float4 groups (128 consecutive elements, 512 B per slab row) x 8 slab lanes;
+// 4 independent 16-B loads in flight per thread, fixed-order LDS combine (deterministic)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WreduceArgs a) {
-  __shared__ float red[8][32];
-  const long long per = (long long)a.ntaps * a.cinp * a.coutp;
+  __shared__ float4 red[8][32];
+  const long long per = (long long)a.ntaps * a.cinp * a.coutp;        // multiple of 1024
   const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const long long idx = (long long)blockIdx.x * 32 + e;
-  float s = 0.f;
+  const long long idx = ((long long)blockIdx.x * 32 + e) * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (idx < per) {
+    const float* base = a.slab + idx;
     int k = sl;
     for (; k + 24 < a.nslabs; k += 32) {
-      const float v0 = a.slab[(long long)k * per + idx], v1 = a.slab[(long long)(k + 8) * per + idx];
-      const float v2 = a.slab[(long long)(k + 16) * per + idx], v3 = a.slab[(long long)(k + 24) * per + idx];
-      s += (v0 + v1) + (v2 + v3);
+      const float4 v0 = *reinterpret_cast<const float4*>(base + (long long)k * per);
+      const float4 v1 = *reinterpret_cast<const float4*>(base + (long long)(k + 8) * per);
+      const float4 v2 = *reinterpret_cast<const float4*>(base + (long long)(k + 16) * per);
+      const float4 v3 = *reinterpret_cast<const float4*>(base + (long long)(k + 24) * per);
+      s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
+      s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
     }
-    for (; k < a.nslabs; k += 8) s += a.slab[(long long)k * per + idx];
+    for (; k < a.nslabs; k += 8) {
+      const float4 v = *reinterpret_cast<const float4*>(base + (long long)k * per);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
   }
   red[sl][e] = s;
   __syncthreads();
   if (sl != 0 || idx >= per) return;
 #pragma unroll
-  for (int q = 1; q < 8; ++q) s += red[q][e];
-  int co = (int)(idx % a.coutp);
-  int ci = (int)((idx / a.coutp) % a.cinp);
-  const int tap = (int)(idx / ((long long)a.coutp * a.cinp));
-  int blk = 0;
-  if (a.s2d_cp) { blk = ci / a.s2d_cp; ci = ci % a.s2d_cp; }
-  if (a.co_cls) { blk = co / a.co_cls; co = co % a.co_cls; }
-  if (co >= a.cout || ci >= a.cin || blk >= 8) return;
-  const int td = tap / (a.ks * a.ks), th = (tap / a.ks) % a.ks, tw = tap % a.ks;
-  const long long dst = co * a.s_co + ci * a.s_ci + (a.tb0 + a.ts0 * td + (blk >> 2)) * a.s_k0 +
-                        (a.tb1 + a.ts1 * th + ((blk >> 1) & 1)) * a.s_k1 + (a.tb2 + a.ts2 * tw + (blk & 1)) * a.s_k2;
-  if (a.accumulate) a.dw[dst] += s; else a.dw[dst] = s;
+  for (int q = 1; q < 8; ++q) {
+    const float4 v = red[q][e];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const float f[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long long id = idx + j;
+    int co = (int)(id % a.coutp);
+    int ci = (int)((id / a.coutp) % a.cinp);
+    const int tap = (int)(id / ((long long)a.coutp * a.cinp));
+    int blk = 0;
+    if (a.s2d_cp) { blk = ci / a.s2d_cp; ci = ci % a.s2d_cp; }
+    if (a.co_cls) { blk = co / a.co_cls; co = co % a.co_cls; }
+    if (co >= a.cout || ci >= a.cin || blk >= 8) continue;
+    const int td = tap / (a.ks * a.ks), th = (tap / a.ks) % a.ks, tw = tap % a.ks;
+    const long long dst = co * a.s_co + ci * a.s_ci + (a.tb0 + a.ts0 * td + (blk >> 2)) * a.s_k0 +
+                          (a.tb1 + a.ts1 * th + ((blk >> 1) & 1)) * a.s_k1 + (a.tb2 + a.ts2 * tw + (blk & 1)) * a.s_k2;
+    if (a.accumulate) a.dw[dst] += f[j]; else a.dw[dst] = f[j];
+  }
 }
 
 
@@ -406,6 +422,6 @@ extern "C" int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream) {
   q.s2d_cp = d->s2d_cp;
   q.co_cls = d->g_cls_cout;
   const long long per = (long long)q.ntaps * q.cinp * q.coutp;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 31) / 32)), dim3(256), 0, st, q);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 127) / 128)), dim3(256), 0, st, q);
   return mi355_check_launch("wgrad_reduce");
 }

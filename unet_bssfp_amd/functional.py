@@ -46,6 +46,20 @@ class LayerCache:
         self._store.clear()
 
 
+_ZEROS = {}
+
+
+def _cached_zeros(n: int, device) -> torch.Tensor:
+    """Shared read-only zero vector (exact-zero bias gradients): no fill kernel per layer.  Sharing is safe
+    because every contribution ever accumulated into it is itself zero."""
+    key = (n, device)
+    t = _ZEROS.get(key)
+    if t is None:
+        t = torch.zeros((n,), dtype=torch.float32, device=device)
+        _ZEROS[key] = t
+    return t
+
+
 def _padded(vec: Optional[torch.Tensor], n: int, fill: float = 0.0) -> Optional[torch.Tensor]:
     if vec is None:
         return None
@@ -316,7 +330,7 @@ class ConvFn(Function):
                                    spec.cout, spec.cin, 8, spec.cout * 8, (4, 2, 1), cls, (0, 0, 0))
         if ctx.has_bias and ctx.needs_input_grad[3]:
             if ctx.zero_bias_grad:
-                db = torch.zeros((spec.cout,), dtype=torch.float32, device=dev)
+                db = _cached_zeros(spec.cout, dev)
             else:
                 db = ops.colsum(dz)[: spec.cout].contiguous()
         return dx0, dx1, dw, db, None, None, None, None
