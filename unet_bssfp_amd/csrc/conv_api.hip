@@ -85,7 +85,7 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
     // group => split the contraction over blockIdx.z and combine in a second kernel
     const long long wgs = p->tiles * (d->coutp / (32 * p->ct));
     const int nchunks = (d->c0 + d->c1) / 16;
-    if (wgs < 512 && nchunks >= 8) {
+    if ((wgs < 256 && nchunks >= 8) || (wgs < 512 && nchunks >= 16)) {   // (32^3 x 128 ch measured slower split)
       long long ks = (1024 + wgs - 1) / wgs;
       if (ks > nchunks / 2) ks = nchunks / 2;
       if (ks > 32) ks = 32;
@@ -134,7 +134,7 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
   dim3 block(p.halo && p.shape == 6 ? 512 : 256);
 #define HALO(KS, TD, TH, TW, CT)                                     \
   do {                                                               \
-    constexpr int lds = conv_halo_lds<T, KS, TD, TH, TW>();          \
+    constexpr int lds = conv_halo_lds<T, KS, TD, TH, TW, CT, 4>();   \
     conv_halo_kernel<T, KS, TD, TH, TW, CT><<<grid, block, lds, st>>>(a); \
   } while (0)
 #define HALO_KS(KS)                                                  \
@@ -156,7 +156,7 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
       if (p.shape == 3) { if constexpr (sizeof(T) == 2) { HALO(3, 4, 4, 32, 1); } }
       else if (p.shape == 6) {
         if constexpr (sizeof(T) == 2) {
-          constexpr int lds = conv_halo_lds<T, 3, 4, 4, 32>();
+          constexpr int lds = conv_halo_lds<T, 3, 4, 4, 32, 2, 8>();
           if (p.ct == 2) conv_halo_kernel<T, 3, 4, 4, 32, 2, 8><<<grid, block, lds, st>>>(a);
           else conv_halo_kernel<T, 3, 4, 4, 32, 1, 8><<<grid, block, lds, st>>>(a);
         }

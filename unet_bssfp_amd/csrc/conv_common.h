@@ -118,6 +118,43 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, f32x16 (&a
     bias[ct] = (a.bias && co < a.cstore) ? a.bias[co] : 0.f;
     yp[ct] = co < a.cstore ? reinterpret_cast<T*>(a.y) + co : nullptr;
   }
+#ifdef MI355_NARROW_STORE
+  if constexpr (false) {
+#else
+  if constexpr (sizeof(T) == 2) {
+#endif
+    // 16-bit outputs: a lane owns ONE channel of 16 voxels, so direct stores would be 2 bytes per lane
+    // (32 store instructions per subtile, store-issue bound).  Transpose each 32x32 tile through a
+    // wave-private LDS patch and write 16 bytes per lane: 2 store instructions per tile, whole 64-B rows.
+    __syncthreads();                                        // the halo in LDS is dead for every wave
+    char* wbuf = reinterpret_cast<char*>(red) + wave * 2048;
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int m = acc_row(i, h);
+          const float v = acc[vt][ct][i];
+          const int m0 = (i & 3) + 8 * (i >> 2);
+          const bool ok = to.dvalid[vt] && (m0 / TW) < to.hleft[vt] && (m0 % TW) + 4 * h < to.wleft[vt];
+          if (ok) { s1[ct] += v; s2[ct] += v * v; }
+          *reinterpret_cast<uint16_t*>(wbuf + m * 64 + r * 2) = f32_to_bf16_bits(v + bias[ct]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS writes have landed (in-order LDS)
+        const int co0 = co_base + ct * 32 + (lane & 3) * 8;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          const int v = pass * 16 + (lane >> 2);
+          const int rh = v / TW, cw = v % TW;
+          const uint4 val = *reinterpret_cast<const uint4*>(wbuf + v * 64 + (lane & 3) * 16);
+          if (to.dvalid[vt] && rh < to.hleft[vt] && cw < to.wleft[vt] && co0 + 8 <= a.cstore)
+            *reinterpret_cast<uint4*>(reinterpret_cast<T*>(a.y) + to.base[vt] + rh * to.hstride + cw * to.wstride + co0) = val;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the patch is overwritten
+      }
+    }
+  } else {
 #pragma unroll
   for (int vt = 0; vt < VT; ++vt) {
     if (!to.dvalid[vt]) continue;
@@ -138,14 +175,11 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, f32x16 (&a
           const float v = acc[vt][ct][i];
           s1[ct] += v;
           s2[ct] += v * v;
-#ifdef MI355_EXPERIMENT_NO_STORE
-          asm volatile("" :: "v"(v + bias[ct]));
-#else
           if (yp[ct]) Elem<T>::store(yp[ct] + off, v + bias[ct]);
-#endif
         }
       }
     }
+  }
   }
   if (a.stats) {
 #pragma unroll

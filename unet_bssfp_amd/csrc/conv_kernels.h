@@ -17,7 +17,7 @@
 #include "conv_common.h"
 
 template <typename T, int KS, int TD, int TH, int TW, int CT, int NW = 4>
-__global__ __launch_bounds__(NW * 64) void conv_halo_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && CT == 2 && NW == 4) ? 3 : 1) void conv_halo_kernel(const ConvArgs a) {
   constexpr int ES = sizeof(T);
   constexpr int RS = 32 / TW;                 // rows (h) per 32-voxel subtile
   constexpr int SPD = TH / RS;                // subtiles per d-slice
@@ -256,10 +256,13 @@ __global__ __launch_bounds__(256) void conv_ksplit_reduce_kernel(const ConvArgs 
   }
 }
 
-template <typename T, int KS, int TD, int TH, int TW>
+template <typename T, int KS, int TD, int TH, int TW, int CT = 2, int NW = 4>
 constexpr int conv_halo_lds() {
-  // staging halo, or the 4*CT*64 floats of the statistics reduction (always smaller)
-  return (TD + KS - 1) * (TH + KS - 1) * (TW + KS - 1) * (16 * (int)sizeof(T) + 16);
+  // staging halo; reused by the epilogue for the statistics reduction and (16-bit outputs) the
+  // per-wave 32x32 transposition patches
+  constexpr int halo = (TD + KS - 1) * (TH + KS - 1) * (TW + KS - 1) * (16 * (int)sizeof(T) + 16);
+  constexpr int patch = NW * 2048 > NW * CT * 512 ? NW * 2048 : NW * CT * 512;   // transposition patches / stats
+  return halo > patch ? halo : patch;
 }
 
 // ------------------------------------------------------------------------------------------
