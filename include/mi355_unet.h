@@ -93,6 +93,8 @@ typedef struct mi355_wpack_desc {
   int32_t s2d_mode, s2d_cp;
 } mi355_wpack_desc;
 int mi355_weight_pack(const mi355_wpack_desc* d, void* stream);
+/* n packings in ceil(n/16) launches (descriptors travel by value; all must share one dtype) */
+int mi355_weight_pack_multi(const mi355_wpack_desc* descs, int32_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Implicit-GEMM 3D convolution on MFMA (forward of Conv3d; data-gradient of Conv3d and

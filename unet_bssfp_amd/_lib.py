@@ -63,6 +63,7 @@ _SIGNATURES = {
     "mi355_pack_ncdhw_s2d": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mi355_unpack_ncdhw_s2d": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mi355_weight_pack": (C.c_int, [C.POINTER(WpackDesc), _vp]),
+    "mi355_weight_pack_multi": (C.c_int, [C.POINTER(WpackDesc), _i32, _vp]),
     "mi355_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), _vp]),
     "mi355_conv_workspace_bytes": (_i64, [C.POINTER(ConvDesc)]),
     "mi355_conv_plan_id": (C.c_int, [C.POINTER(ConvDesc)]),

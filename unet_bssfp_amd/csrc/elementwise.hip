@@ -83,6 +83,33 @@ __global__ __launch_bounds__(256) void wpack_kernel(const WpackArgs a) {
   Elem<T>::store(reinterpret_cast<T*>(a.dst) + idx, v);
 }
 
+constexpr int kWpackChunk = 16;
+struct WpackMulti { WpackArgs a[kWpackChunk]; };
+template <typename T>
+__global__ __launch_bounds__(256) void wpack_multi_kernel(const WpackMulti m) {
+  const WpackArgs& a = m.a[blockIdx.y];
+  const int ntaps = a.ks * a.ks * a.ks;
+  const long long total = (long long)(a.cinp / 16) * ntaps * a.coutp * 16;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
+    const int e = (int)(idx % 16);
+    const int co = (int)((idx / 16) % a.coutp);
+    const int tap = (int)((idx / (16ll * a.coutp)) % ntaps);
+    const int chunk = (int)(idx / (16ll * a.coutp * ntaps));
+    int ci = chunk * 16 + e;
+    int cor = co, blk = 0;
+    if (a.s2d_mode == 1) { blk = ci / a.s2d_cp; ci = ci % a.s2d_cp; }
+    if (a.s2d_mode == 2) { blk = cor / a.s2d_cp; cor = cor % a.s2d_cp; }
+    float v = 0.f;
+    if (cor < a.cout && ci < a.cin && blk < 8) {
+      const int td = tap / (a.ks * a.ks), th = (tap / a.ks) % a.ks, tw = tap % a.ks;
+      v = a.src[cor * a.s_co + ci * a.s_ci + (a.tb0 + a.ts0 * td + (blk >> 2)) * a.s_k0 +
+                (a.tb1 + a.ts1 * th + ((blk >> 1) & 1)) * a.s_k1 + (a.tb2 + a.ts2 * tw + (blk & 1)) * a.s_k2];
+    }
+    Elem<T>::store(reinterpret_cast<T*>(a.dst) + idx, v);
+  }
+}
+
 // ------------------------------------------------------------------ channel statistics
 // One block = up to kRowsPerStatBlock rows of one group.  Thread = (row-in-pass, 16-B piece).
 // f(row values) is supplied by the functor; sums of two quantities per channel are produced.
@@ -669,6 +696,45 @@ int mi355_weight_pack(const mi355_wpack_desc* d, void* stream) {
   if (d->dtype == MI355_DT_F32) hipLaunchKernelGGL(wpack_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(wpack_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
   return mi355_check_launch("weight_pack");
+}
+
+static int fill_wpack(const mi355_wpack_desc* d, WpackArgs* a) {
+  MI355_REQUIRE(d && d->src && d->dst, "weight_pack: null pointer");
+  MI355_REQUIRE(d->coutp % 32 == 0 && d->cinp % 16 == 0 && d->cout <= d->coutp && d->cin <= d->cinp && d->ks >= 1 && d->ks <= 4,
+                "weight_pack: bad extents");
+  MI355_REQUIRE(d->s2d_mode >= 0 && d->s2d_mode <= 2 && (d->s2d_mode == 0 || (d->s2d_cp > 0 && d->s2d_cp % 16 == 0)),
+                "weight_pack: bad space-to-depth mode");
+  a->src = d->src; a->dst = d->dst; a->cout = d->cout; a->cin = d->cin; a->coutp = d->coutp; a->cinp = d->cinp; a->ks = d->ks;
+  a->s_co = d->s_co; a->s_ci = d->s_ci; a->s_k0 = d->s_k[0]; a->s_k1 = d->s_k[1]; a->s_k2 = d->s_k[2];
+  a->tb0 = d->tbase[0]; a->tb1 = d->tbase[1]; a->tb2 = d->tbase[2];
+  a->ts0 = d->tstep[0]; a->ts1 = d->tstep[1]; a->ts2 = d->tstep[2];
+  a->s2d_mode = d->s2d_mode; a->s2d_cp = d->s2d_cp;
+  return MI355_OK;
+}
+
+int mi355_weight_pack_multi(const mi355_wpack_desc* descs, int32_t n, void* stream) {
+  MI355_REQUIRE(descs && n > 0, "weight_pack_multi: bad argument");
+  const int dtype = descs[0].dtype;
+  MI355_REQUIRE(dtype == MI355_DT_F32 || dtype == MI355_DT_BF16, "weight_pack_multi: bad dtype");
+  for (int base = 0; base < n; base += kWpackChunk) {
+    const int cnt = n - base < kWpackChunk ? n - base : kWpackChunk;
+    WpackMulti m;
+    long long mx = 0;
+    for (int i = 0; i < kWpackChunk; ++i) {
+      const mi355_wpack_desc* d = &descs[base + (i < cnt ? i : 0)];
+      MI355_REQUIRE(d->dtype == dtype, "weight_pack_multi: mixed dtypes");
+      int rc = fill_wpack(d, &m.a[i]);
+      if (rc) return rc;
+      const long long total = (long long)d->cinp * d->ks * d->ks * d->ks * d->coutp;
+      if (i < cnt && total > mx) mx = total;
+    }
+    long long nb = (mx + 256 * 8 - 1) / (256 * 8);
+    if (nb > 512) nb = 512;
+    dim3 grid((unsigned)nb, cnt);
+    if (dtype == MI355_DT_F32) hipLaunchKernelGGL(wpack_multi_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, m);
+    else hipLaunchKernelGGL(wpack_multi_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, m);
+  }
+  return mi355_check_launch("weight_pack_multi");
 }
 
 int32_t mi355_channel_stats_blocks(int64_t rows_per_group) {

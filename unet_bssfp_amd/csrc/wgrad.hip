@@ -336,7 +336,7 @@ int wplan(const mi355_wgrad_desc* d, WPlan* p) {
                          d->c1 == 0 && d->cout <= d->g_cls_cout),
                 "wgrad: bad transposed-conv class folding");
   p->fast = d->dtype == MI355_DT_BF16 && d->stride == 1 && d->ld0 % 8 == 0 && (d->c1 == 0 || d->ld1 % 8 == 0) && d->ldg % 8 == 0 &&
-            (cls || ((d->ks == 3 || d->ks == 2) && d->gs == 1 && d->goff[0] == 0 && d->goff[1] == 0 && d->goff[2] == 0 &&
+            (cls || (d->ks <= 3 && d->gs == 1 && d->goff[0] == 0 && d->goff[1] == 0 && d->goff[2] == 0 &&
                      d->gd == d->do_ && d->gh == d->ho && d->gw == d->wo));
   if (p->fast) {
     p->shape = d->wo > 16 ? 0 : 1;

@@ -29,21 +29,47 @@ class LayerCache:
     """Packed-weight cache of one convolution (re-packed when the parameter changes)."""
 
     def __init__(self):
-        self._store = {}
+        self._store = {}          # key -> [tag, value, weight tensor, pack descriptor]
+
+    @staticmethod
+    def _tag(tensor):
+        return (tensor._version, tensor.data_ptr(), tensor.device, _WEIGHT_EPOCH)
 
     def get(self, key, tensor: torch.Tensor, builder):
         """builder(reuse) -> (packed, coutp, cinp); `reuse` is the previous buffer (re-packed in place so
         that its address stays stable across steps -- a captured hipGraph keeps pointing at it)."""
-        tag = (tensor._version, tensor.data_ptr(), tensor.device, _WEIGHT_EPOCH)
+        tag = self._tag(tensor)
         hit = self._store.get(key)
         if hit is not None and hit[0] == tag:
             return hit[1]
         val = builder(hit[1][0] if hit is not None else None)
-        self._store[key] = (tag, val)
+        self._store[key] = [tag, val, tensor, ops.LAST_WPACK_DESC[0]]
         return val
+
+    def stale(self):
+        """Entries whose weights changed since they were packed (and whose buffers can be re-packed in place)."""
+        return [e for e in self._store.values() if e[0] != self._tag(e[2]) and e[3] is not None and e[3].dst == e[1][0].data_ptr()
+                and e[3].src == e[2].data_ptr()]
 
     def clear(self):
         self._store.clear()
+
+
+def repack_weights(module: torch.nn.Module):
+    """Re-pack, in a few batched launches, every packed-weight buffer of `module` that is out of date
+    (call right after an optimiser step: the following forward/backward then finds all caches fresh)."""
+    by_dtype = {}
+    entries = []
+    for m in module.modules():
+        spec = getattr(m, "spec", None)
+        if isinstance(spec, ConvSpec):
+            for e in spec.cache.stale():
+                by_dtype.setdefault(e[3].dtype, []).append(e[3])
+                entries.append(e)
+    for descs in by_dtype.values():
+        ops.weight_pack_multi(descs)
+    for e in entries:
+        e[0] = LayerCache._tag(e[2])
 
 
 _ZEROS = {}

@@ -110,6 +110,13 @@ class bSSFPToDWITensorModel(nn.Module):
         return (loss + loss_hat) / 2
 
     @staticmethod
+    def _repack(module: nn.Module):
+        """Batched re-pack of the network's packed weights right after its optimiser step (HIP modules only)."""
+        if next(module.parameters()).is_cuda:
+            from .functional import repack_weights
+            repack_weights(module)
+
+    @staticmethod
     def _toggle(module: nn.Module, flag: bool):
         for p in module.parameters():
             p.requires_grad_(flag)
@@ -133,6 +140,7 @@ class bSSFPToDWITensorModel(nn.Module):
         gen_opt, _ = self.optimizers()
         gen_opt.step()
         gen_opt.zero_grad()
+        self._repack(self.gen)
         self._toggle(self.discr, True)
         self._toggle(self.gen, False)
         loss = self._discr_step(x, y)
@@ -144,6 +152,7 @@ class bSSFPToDWITensorModel(nn.Module):
         _, discr_opt = self.optimizers()
         discr_opt.step()
         discr_opt.zero_grad()
+        self._repack(self.discr)
         self._toggle(self.gen, True)
 
     def training_step(self, batch, batch_idx=0):

@@ -144,7 +144,19 @@ def weight_pack(src: torch.Tensor, cout: int, cin: int, ks: int, s_co: int, s_ci
     d.dtype = _DT[dtype]
     d.s2d_mode, d.s2d_cp = s2d_mode, s2d_cp
     _lib.check(_lib.load().mi355_weight_pack(C.byref(d), _stream()), "weight_pack")
+    LAST_WPACK_DESC[0] = d
     return dst, coutp, cinp
+
+
+LAST_WPACK_DESC = [None]      # descriptor of the latest weight_pack (picked up by the layer cache for batched re-packs)
+
+
+def weight_pack_multi(descs):
+    """Re-run a list of earlier packings (same sources / destinations) in a few launches."""
+    if not descs:
+        return
+    arr = (_lib.WpackDesc * len(descs))(*descs)
+    _lib.check(_lib.load().mi355_weight_pack_multi(arr, len(descs), _stream()), "weight_pack_multi")
 
 
 # ------------------------------------------------------------------------------ convolution
