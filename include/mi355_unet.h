@@ -117,7 +117,7 @@ typedef struct mi355_conv_desc {
   int32_t pad[3];
   const void* wp;                 /* packed weights, see mi355_weight_pack */
   int32_t coutp;
-  const float* bias;              /* [coutp] f32 or NULL */
+  const float* bias;              /* f32 [nbias] or NULL; channels >= nbias get no bias */
   void* y; int32_t ldy; int32_t cstore;
   int32_t dy, hy, wy;             /* physical output extents          */
   int32_t os; int32_t ooff[3];
@@ -130,6 +130,7 @@ typedef struct mi355_conv_desc {
    * blk*cls_cout + co is stored at output position 2p + (bd,bh,bw) (os must be 2), channel co.
    * 0 = off.  Weights: mi355_weight_pack with s2d_mode 2, s2d_cp = cls_cout. */
   int32_t cls_cout;
+  int32_t nbias;                  /* length of bias (0: coutp, for callers that pad it) */
 } mi355_conv_desc;
 int mi355_conv_fwd(const mi355_conv_desc* d, void* stream);
 int64_t mi355_conv_workspace_bytes(const mi355_conv_desc* d);
@@ -187,7 +188,7 @@ int32_t mi355_channel_stats_blocks(int64_t rows_per_group);
  * the mean (conv bias when partials were taken before the bias add).  Optionally updates
  * BatchNorm running stats: rm = (1-mom)*rm + mom*mean, rv = (1-mom)*rv + mom*var*cnt/(cnt-1). */
 int mi355_norm_finalize(const float* part, int32_t parts_per_group, int32_t groups, int32_t c,
-                        int64_t count_per_group, const float* shift, float eps,
+                        int64_t count_per_group, const float* shift, int32_t n_real, float eps,
                         float* mean, float* rstd,
                         float* running_mean, float* running_var, float momentum, void* stream);
 
@@ -215,6 +216,7 @@ typedef struct mi355_normact_desc {
   /* optional DEVICE pointer to a 64-bit step counter mixed into the dropout seed (`seed` is then a
    * per-call salt): a launch captured in a hipGraph draws a new mask on every replay */
   const uint64_t* seed_ptr;
+  int32_t n_affine;               /* length of gamma/beta (0: c); channels beyond it use gamma 0, beta 0 */
 } mi355_normact_desc;
 int mi355_normact_fwd(const mi355_normact_desc* d, void* stream);
 int mi355_normact_bwd_reduce(const mi355_normact_desc* d, void* stream);

@@ -30,7 +30,7 @@ class ConvDesc(C.Structure):
                 ("pad", _i32 * 3), ("wp", _vp), ("coutp", _i32), ("bias", _vp),
                 ("y", _vp), ("ldy", _i32), ("cstore", _i32), ("dy", _i32), ("hy", _i32), ("wy", _i32),
                 ("os", _i32), ("ooff", _i32 * 3), ("stats_part", _vp), ("dtype", _i32),
-                ("workspace", _vp), ("workspace_bytes", _i64), ("cls_cout", _i32)]
+                ("workspace", _vp), ("workspace_bytes", _i64), ("cls_cout", _i32), ("nbias", _i32)]
 
 
 class WgradDesc(C.Structure):
@@ -52,7 +52,8 @@ class NormActDesc(C.Structure):
                 ("slope", _f32), ("drop_p", _f32), ("seed", _u64), ("dtype", _i32),
                 ("da", _vp), ("ldda", _i32), ("dz", _vp), ("lddz", _i32),
                 ("part", _vp), ("blocks_per_group", _i32), ("sums", _vp), ("batch_stats", _i32),
-                ("s2d_a", _i32), ("s2d_da", _i32), ("sd", _i32), ("sh", _i32), ("sw", _i32), ("seed_ptr", _vp)]
+                ("s2d_a", _i32), ("s2d_da", _i32), ("sd", _i32), ("sh", _i32), ("sw", _i32), ("seed_ptr", _vp),
+                ("n_affine", _i32)]
 
 
 _SIGNATURES = {
@@ -72,7 +73,7 @@ _SIGNATURES = {
     "mi355_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc), _vp]),
     "mi355_channel_stats": (C.c_int, [_vp, _i32, _i32, _i64, _i32, _vp, _i32, _i32, _vp]),
     "mi355_channel_stats_blocks": (_i32, [_i64]),
-    "mi355_norm_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i64, _vp, _f32, _vp, _vp, _vp, _vp, _f32, _vp]),
+    "mi355_norm_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i64, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _f32, _vp]),
     "mi355_normact_fwd": (C.c_int, [C.POINTER(NormActDesc), _vp]),
     "mi355_normact_bwd_reduce": (C.c_int, [C.POINTER(NormActDesc), _vp]),
     "mi355_normact_bwd_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),

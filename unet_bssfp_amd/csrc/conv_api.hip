@@ -124,6 +124,7 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
   a.m_total = (long long)d->n * d->do_ * d->ho * d->wo;
   a.ksplit = p.ksplit;
   a.cls_cout = d->cls_cout;
+  a.nbias = d->nbias > 0 ? d->nbias : d->coutp;
   a.kslab = (float*)d->workspace;
   if (p.ksplit > 1) {
     const long long need = (long long)p.ksplit * a.m_total * d->coutp * 4;

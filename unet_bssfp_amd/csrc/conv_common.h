@@ -20,6 +20,7 @@ struct ConvArgs {
   int ksplit;                      // halo kernel: contraction split over blockIdx.z (1 = off)
   float* kslab;                    // [ksplit][n*do*ho*wo][coutp] f32 partial sums
   int cls_cout;                    // gather kernel: transposed-conv classes folded into the cout index (0 = off)
+  int nbias;                       // entries of bias
 };
 
 // Epilogue shared by both kernels.
@@ -54,7 +55,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[V
           s1[ct] += v;
           s2[ct] += v * v;
           if (co < a.cstore) {
-            const float b = a.bias ? a.bias[co] : 0.f;
+            const float b = (a.bias && co < a.nbias) ? a.bias[co] : 0.f;
             Elem<T>::store(reinterpret_cast<T*>(a.y) + off + co, v + b);
           }
         }
@@ -115,7 +116,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, f32x16 (&a
   for (int ct = 0; ct < CT; ++ct) {
     s1[ct] = 0.f; s2[ct] = 0.f;
     const int co = co_base + ct * 32 + r;
-    bias[ct] = (a.bias && co < a.cstore) ? a.bias[co] : 0.f;
+    bias[ct] = (a.bias && co < a.nbias) ? a.bias[co] : 0.f;
     yp[ct] = co < a.cstore ? reinterpret_cast<T*>(a.y) + co : nullptr;
   }
 #ifdef MI355_NARROW_STORE

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void conv_ksplit_reduce_kernel(const ConvArgs 
   float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
   float bias[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) bias[j] = (a.bias && ch0 + j < a.cstore) ? a.bias[ch0 + j] : 0.f;
+  for (int j = 0; j < 4; ++j) bias[j] = (a.bias && ch0 + j < a.nbias) ? a.bias[ch0 + j] : 0.f;
   const long long r0 = (long long)blockIdx.x * rpb;
   if (rsub < rpp)
     for (long long row = r0 + rsub; row < r0 + rpb && row < a.m_total; row += rpp) {

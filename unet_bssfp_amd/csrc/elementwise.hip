@@ -206,7 +206,7 @@ __device__ __forceinline__ void block_sum_parts(const float* __restrict__ part, 
 
 __global__ __launch_bounds__(1024) void norm_finalize_kernel(const float* __restrict__ part, int ppg, int c,
                                                              long long count, const float* __restrict__ shift,
-                                                             float eps, float* __restrict__ mean,
+                                                             int n_real, float eps, float* __restrict__ mean,
                                                              float* __restrict__ rstd, float* running_mean,
                                                              float* running_var, float momentum) {
   const int g = blockIdx.y;
@@ -218,10 +218,10 @@ __global__ __launch_bounds__(1024) void norm_finalize_kernel(const float* __rest
   const double m = s1 / (double)count;
   double var = s2 / (double)count - m * m;
   if (var < 0.0) var = 0.0;
-  const double mu = m + (shift ? (double)shift[ch] : 0.0);
+  const double mu = m + ((shift && ch < n_real) ? (double)shift[ch] : 0.0);
   mean[(long long)g * c + ch] = (float)mu;
   rstd[(long long)g * c + ch] = (float)(1.0 / sqrt(var + (double)eps));
-  if (running_mean) {
+  if (running_mean && ch < n_real) {
     const double unb = count > 1 ? var * (double)count / (double)(count - 1) : var;
     running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mu);
     running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
@@ -259,6 +259,7 @@ struct NormActArgs {
   float slope; float drop_scale; unsigned thr16; unsigned long long seed; const unsigned long long* seed_ptr;
   const char* da; int ldda; char* dz; int lddz;
   float* part; int blocks_per_group; const float* sums; int batch_stats;
+  int n_affine;   // entries of gamma / beta
   S2D s2d_a;      // forward: write `a` in space-to-depth layout
   S2D s2d_da;     // backward: read `da` from a space-to-depth tensor
 };
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256) void normact_fwd_kernel(const NormActArgs q) {
 #pragma unroll
   for (int j = 0; j < EPV; ++j) {
     const int ch = ch0 + j;
-    const float ga = q.gamma ? q.gamma[ch] : 1.f, be = q.beta ? q.beta[ch] : 0.f;
+    const float ga = q.gamma ? (ch < q.n_affine ? q.gamma[ch] : 0.f) : 1.f, be = (q.beta && ch < q.n_affine) ? q.beta[ch] : 0.f;
     if (q.mean) {
       const float rs = q.rstd[(long long)g * q.c + ch], mu = q.mean[(long long)g * q.c + ch];
       sc[j] = ga * rs;
@@ -310,8 +311,8 @@ __device__ __forceinline__ void load_bwd_const(const NormActArgs& q, int g, int 
     const int ch = ch0 + j;
     k.mu[j] = q.mean ? q.mean[(long long)g * q.c + ch] : 0.f;
     k.rs[j] = q.mean ? q.rstd[(long long)g * q.c + ch] : 1.f;
-    k.ga[j] = q.gamma ? q.gamma[ch] : 1.f;
-    k.be[j] = q.beta ? q.beta[ch] : 0.f;
+    k.ga[j] = q.gamma ? (ch < q.n_affine ? q.gamma[ch] : 0.f) : 1.f;
+    k.be[j] = (q.beta && ch < q.n_affine) ? q.beta[ch] : 0.f;
   }
 }
 // g = da * dropout * lrelu'(pre);  xhat = (z - mean) * rstd  (xhat = z when there is no norm)
@@ -761,12 +762,12 @@ int mi355_channel_stats(const void* x, int32_t ld, int32_t c, int64_t rows_per_g
 }
 
 int mi355_norm_finalize(const float* part, int32_t parts_per_group, int32_t groups, int32_t c, int64_t count_per_group,
-                        const float* shift, float eps, float* mean, float* rstd, float* running_mean,
+                        const float* shift, int32_t n_real, float eps, float* mean, float* rstd, float* running_mean,
                         float* running_var, float momentum, void* stream) {
   MI355_REQUIRE(part && mean && rstd && parts_per_group > 0 && groups > 0 && c > 0 && count_per_group > 0, "norm_finalize: bad argument");
   MI355_REQUIRE(!running_mean || (running_var && groups == 1), "norm_finalize: running stats need groups == 1");
   hipLaunchKernelGGL(norm_finalize_kernel, dim3((c + 7) / 8, groups), dim3(1024), 0, (hipStream_t)stream, part,
-                     parts_per_group, c, (long long)count_per_group, shift, eps, mean, rstd, running_mean, running_var, momentum);
+                     parts_per_group, c, (long long)count_per_group, shift, n_real > 0 ? n_real : c, eps, mean, rstd, running_mean, running_var, momentum);
   return mi355_check_launch("norm_finalize");
 }
 
@@ -791,6 +792,7 @@ static int fill_normact(const mi355_normact_desc* d, NormActArgs* q, const char*
   q->drop_scale = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
   q->seed = d->seed;
   q->seed_ptr = (const unsigned long long*)d->seed_ptr;
+  q->n_affine = d->n_affine > 0 ? d->n_affine : d->c;
   q->da = (const char*)d->da; q->ldda = d->ldda; q->dz = (char*)d->dz; q->lddz = d->lddz;
   q->part = d->part; q->blocks_per_group = d->blocks_per_group; q->sums = d->sums; q->batch_stats = d->batch_stats;
   q->s2d_a = S2D{0, 0, 0, 0};

@@ -262,7 +262,7 @@ class ConvFn(Function):
         part = None
         if s2d_cp:
             wp, coutp, _ = spec.w_fwd_s2d(weight, dtype, s2d_cp)
-            bp = _padded(bias, coutp)
+            bp = bias.detach() if bias is not None else None
             if want_stats:
                 tiles, _ = ops.conv_num_tiles(x0, None, wp, coutp, 2, 1, (0, 0, 0), out, (do_, ho, wo))
                 part = torch.empty((tiles, 2, coutp), dtype=torch.float32, device=dev)
@@ -270,7 +270,7 @@ class ConvFn(Function):
                          real=(spec.cin, spec.cout))
         elif spec.kind == "conv":
             wp, coutp, _ = spec.w_fwd(weight, dtype, c0 + c1)
-            bp = _padded(bias, coutp)
+            bp = bias.detach() if bias is not None else None
             pad3 = (spec.pad,) * 3
             if want_stats:
                 tiles, _ = ops.conv_num_tiles(x0, x1, wp, coutp, spec.ks, spec.stride, pad3, out, (do_, ho, wo))
@@ -282,12 +282,12 @@ class ConvFn(Function):
             if spec.cout % 64 == 0:
                 # the 8 parity classes folded into the column index of one 1x1x1 GEMM (8*Cout columns)
                 wp, coutp, _ = spec.w_deconv_fwd_all(weight, dtype, c0)
-                ops.conv_fwd(x0, None, wp, coutp, _padded(bias, spec.cout), 1, 1, (0, 0, 0), out, (di, hi, wi), os=2,
+                ops.conv_fwd(x0, None, wp, coutp, bias.detach() if bias is not None else None, 1, 1, (0, 0, 0), out, (di, hi, wi), os=2,
                              real=(spec.cin, 8 * spec.cout), cls_cout=spec.cout)
             else:
                 for cls in CLASSES8:
                     wp, coutp, _ = spec.w_deconv_fwd(weight, dtype, c0, cls)
-                    bp = _padded(bias, coutp)
+                    bp = bias.detach() if bias is not None else None
                     ops.conv_fwd(x0, None, wp, coutp, bp, 1, 1, (0, 0, 0), out, (di, hi, wi), os=2, ooff=cls,
                                  real=(spec.cin, spec.cout))
         ctx.save_for_backward(x0, x1, weight)
@@ -421,25 +421,21 @@ class NormActFn(Function):
                 if part is not None and part.numel() > 0:
                     assert part.shape[2] == c, "fused statistics need coutp == padded channels"
                     ppg = part.shape[0] // groups
-                    shift = _padded(conv_bias, c)
+                    shift = conv_bias.detach() if conv_bias is not None else None
                 else:
                     part, ppg = ops.channel_stats(z, groups)
                     shift = None
                 upd = cfg.kind == "batch" and training and running_mean is not None
-                rm = rv = None
-                if upd:
-                    # running buffers may be shorter than the padded channel count
-                    rm = running_mean if running_mean.numel() == c else _padded(running_mean, c)
-                    rv = running_var if running_var.numel() == c else _padded(running_var, c, 1.0)
-                mean, rstd = ops.norm_finalize(part, ppg, groups, c, rows // groups, shift, cfg.eps, rm, rv, cfg.momentum)
-                if upd and rm is not running_mean:
-                    running_mean.copy_(rm[: running_mean.numel()])
-                    running_var.copy_(rv[: running_var.numel()])
+                n_real = running_mean.numel() if upd else (shift.numel() if shift is not None else 0)
+                mean, rstd = ops.norm_finalize(part, ppg, groups, c, rows // groups, shift, cfg.eps,
+                                               running_mean if upd else None, running_var if upd else None,
+                                               cfg.momentum, n_real=n_real)
                 batch_stats = True
             else:
                 mean = _padded(running_mean, c).reshape(1, c)
                 rstd = torch.rsqrt(_padded(running_var, c, 1.0) + cfg.eps).reshape(1, c)
-        gp, bp = _padded(gamma, c), _padded(beta, c)
+        gp = gamma.detach() if gamma is not None else None      # kernels guard the (possibly shorter) length
+        bp = beta.detach() if beta is not None else None
         p = cfg.p if training else 0.0
         seed = DropoutState.next_salt() if p > 0.0 else 0
         seed_t = DropoutState.base(z.device) if p > 0.0 else None

@@ -175,6 +175,7 @@ def _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, st
     d.pad = (C.c_int32 * 3)(*pad)
     d.wp, d.coutp = wp.data_ptr(), coutp
     d.bias = _ptr(bias)
+    d.nbias = bias.numel() if bias is not None else 0
     d.y, d.ldy, d.cstore = out.data_ptr(), act_ld(out), out.shape[4]
     d.dy, d.hy, d.wy = out.shape[1:4]
     d.os = os
@@ -201,7 +202,7 @@ def conv_fwd(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os=1, ooff=(0,
              cls_cout=0):
     require_cuda(x0, x1, wp, bias, out, stats)
     assert out.dtype == x0.dtype and wp.dtype == x0.dtype
-    assert bias is None or (bias.dtype == torch.float32 and bias.numel() >= (cls_cout or coutp))
+    assert bias is None or (bias.dtype == torch.float32 and bias.is_contiguous())
     d = _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, stats, cls_cout)
     lib = _lib.load()
     need = lib.mi355_conv_workspace_bytes(C.byref(d))
@@ -272,10 +273,11 @@ def channel_stats(x: torch.Tensor, groups: int) -> Tuple[torch.Tensor, int]:
 
 
 def norm_finalize(part, parts_per_group, groups, c, count, shift, eps, running_mean=None, running_var=None,
-                  momentum=0.0):
+                  momentum=0.0, n_real=0):
+    """n_real: entries of `shift` / the running buffers when they are shorter than the padded channel count c."""
     mean = torch.empty((groups, c), dtype=torch.float32, device=part.device)
     rstd = torch.empty_like(mean)
-    _lib.check(_lib.load().mi355_norm_finalize(part.data_ptr(), parts_per_group, groups, c, count, _ptr(shift),
+    _lib.check(_lib.load().mi355_norm_finalize(part.data_ptr(), parts_per_group, groups, c, count, _ptr(shift), n_real,
                                                eps, mean.data_ptr(), rstd.data_ptr(), _ptr(running_mean),
                                                _ptr(running_var), momentum, _stream()), "norm_finalize")
     return mean, rstd
@@ -297,6 +299,7 @@ def _normact_desc(z, groups, mean, rstd, gamma, beta, slope, drop_p, seed, seed_
     d.z, d.ldz, d.c = z.data_ptr(), act_ld(z), c
     d.rows_per_group, d.groups = rows // groups, groups
     d.mean, d.rstd, d.gamma, d.beta = _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta)
+    d.n_affine = gamma.numel() if gamma is not None else 0
     d.slope, d.drop_p, d.seed = slope, drop_p, seed
     d.seed_ptr = _ptr(seed_t)
     d.dtype = _DT[z.dtype]
