@@ -35,6 +35,7 @@ extern "C" {
 
 #define MI355_DT_F32 0
 #define MI355_DT_BF16 1
+#define MI355_DT_F64 2   /* mi355_dti_scalar_maps only */
 
 #define MI355_OK 0
 #define MI355_ERR_ARG (-1)
@@ -261,6 +262,23 @@ int mi355_l1_bwd(const float* a, const float* b, int64_t count, const float* gsc
 int mi355_adamw_multi(const void* const* ptrs, const int64_t* sizes, int32_t ntensors,
                       float lr, float beta1, float beta2, float eps, float weight_decay,
                       const int64_t* step_dev, int64_t step, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * DTI scalar maps -- the voxel loop of `do_calc_scalar_maps`
+ * (src/eval.py:73-135): symmetric tensor (Dxx,Dxy,Dxz,Dyy,Dyz,Dzz) -> eigh -> FA, MD, AD, RD,
+ * azimuth, inclination (degrees) and the FA-weighted |principal eigenvector| RGB map.
+ * Component c of voxel v is read at tensor[v*vox_stride + c*comp_stride] (elements of `dtype`,
+ * MI355_DT_F32 or MI355_DT_F64): (X,Y,Z,6) NIfTI order = strides (1, 6); a generator output
+ * [6][D][H][W] = strides (D*H*W, 1).  Each component is first mapped to x*scale + offset, the
+ * min-max de-normalisation of `do_invert_dwi_tensor_norm` (src/eval.py:39-47, scale = |max-min|,
+ * offset = min); pass (1, 0) for none.  Outputs are `dtype` too: six [nvox] maps and rgb [nvox][3].
+ * Arithmetic is f64 like the reference.  The eigenvector sign (arbitrary in LAPACK) is fixed to
+ * z >= 0, so azimuth/inclination agree with the reference up to the antipodal map
+ * (az, inc) ~ (az +- 180, 180 - inc).  A zero tensor gives FA = NaN like numpy's 0/0.
+ * ---------------------------------------------------------------------------------------- */
+int mi355_dti_scalar_maps(const void* tensor, int32_t dtype, int64_t nvox, int64_t comp_stride,
+                          int64_t vox_stride, double scale, double offset, void* fa, void* md, void* ad,
+                          void* rd, void* azimuth, void* inclination, void* rgb, void* stream);
 
 /* layout probe used by the tests: writes lane -> (row, col) maps of the MFMA accumulators */
 int mi355_mfma_selftest(float* out_f32_1024, float* out_bf16_1024, void* stream);

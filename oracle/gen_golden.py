@@ -174,6 +174,27 @@ def case_gan_step(ref, out_dir):
     np.savez_compressed(os.path.join(out_dir, "gan_step.npz"), **store)
 
 
+def case_dti_scalar_maps(ref_root, out_dir):
+    """Runs the reference's OWN voxel loop (src/eval.py:84-116, the three nested `for` loops of
+    do_calc_scalar_maps) on a small synthetic tensor field.  Only the loop statement is extracted (AST);
+    the NIfTI I/O around it needs nibabel and is not executed."""
+    from oracle import dti_ref
+    path = os.path.join(ref_root, "src", "eval.py")
+    with open(path) as fh:
+        tree = ast.parse(fh.read(), filename=path)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "do_calc_scalar_maps")
+    loop = next(n for n in fn.body if isinstance(n, ast.For))
+    data = dti_ref.synthetic_tensor_field((5, 6, 7), seed=3)
+    ns = {"np": np, "data": data}
+    for k in ("fa", "md", "ad", "rd", "azimuth", "inclination"):
+        ns[k] = np.zeros(data.shape[:-1])
+    ns["rgb"] = np.zeros(data.shape[:-1] + (3,))
+    with np.errstate(all="ignore"):
+        exec(compile(ast.Module(body=[loop], type_ignores=[]), path, "exec"), ns)
+    np.savez_compressed(os.path.join(out_dir, "dti_scalar_maps.npz"), data=data,
+                        **{k: ns[k] for k in ("fa", "md", "ad", "rd", "azimuth", "inclination", "rgb")})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -190,6 +211,9 @@ def main():
             continue
         fn(ref, a.out)
         print("wrote", name)
+    if not a.only or a.only == "dti":
+        case_dti_scalar_maps(a.ref, a.out)
+        print("wrote dti")
 
 
 if __name__ == "__main__":
