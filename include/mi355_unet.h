@@ -280,6 +280,29 @@ int mi355_dti_scalar_maps(const void* tensor, int32_t dtype, int64_t nvox, int64
                           int64_t vox_stride, double scale, double offset, void* fa, void* md, void* ad,
                           void* rd, void* azimuth, void* inclination, void* rgb, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Sliding-window inference -- the data movement of `predict_step` /
+ * `test_step` (src/model.py:291-333) around Generator.forward: TorchIO's GridSampler patch
+ * extraction and GridAggregator.add_batch / get_output_tensor (src/data_module.py:168-183).
+ * f32; volume [C][D][H][W], patches [B][C][pd][ph][pw].  Locations are HOST arrays (they travel
+ * by value in the kernel arguments, at most MI355_MAX_PATCHES per launch, longer lists are chunked).
+ *   gather   : origins[b][3] = first voxel of patch b.
+ *   aggregate: locs9[b] = {origin[3], keep_ini[3], keep_fin[3]} in volume coordinates (the kept
+ *              region is the patch minus TorchIO's half-overlap crop); MI355_AGG_CROP assigns, the
+ *              LAST patch of the list covering a voxel wins (the reference's assignment order);
+ *              MI355_AGG_AVERAGE adds into vol and counts into count[D*H*W], both zero-initialised
+ *              by the caller, and mi355_patch_average_finalize divides.  Deterministic (no atomics).
+ * ---------------------------------------------------------------------------------------- */
+#define MI355_MAX_PATCHES 48
+#define MI355_AGG_CROP 0
+#define MI355_AGG_AVERAGE 1
+int mi355_patch_gather(const float* vol, int32_t c, int32_t d, int32_t h, int32_t w, const int32_t* origins,
+                       int32_t npatches, int32_t pd, int32_t ph, int32_t pw, float* out, void* stream);
+int mi355_patch_aggregate(const float* patches, const int32_t* locs9, int32_t npatches, int32_t pd, int32_t ph,
+                          int32_t pw, int32_t mode, float* vol, float* count, int32_t c, int32_t d, int32_t h,
+                          int32_t w, void* stream);
+int mi355_patch_average_finalize(float* vol, const float* count, int32_t c, int64_t voxels, void* stream);
+
 /* layout probe used by the tests: writes lane -> (row, col) maps of the MFMA accumulators */
 int mi355_mfma_selftest(float* out_f32_1024, float* out_bf16_1024, void* stream);
 

@@ -87,6 +87,9 @@ _SIGNATURES = {
     "mi355_adamw_multi": (C.c_int, [_vp, _vp, _i32, _f32, _f32, _f32, _f32, _f32, _vp, _i64, _vp]),
     "mi355_dti_scalar_maps": (C.c_int, [_vp, _i32, _i64, _i64, _i64, C.c_double, C.c_double,
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mi355_patch_gather": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "mi355_patch_aggregate": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mi355_patch_average_finalize": (C.c_int, [_vp, _vp, _i32, _i64, _vp]),
     "mi355_mfma_selftest": (C.c_int, [_vp, _vp, _vp]),
 }
 

@@ -167,6 +167,25 @@ class bSSFPToDWITensorModel(nn.Module):
         self.last_logs = logs
         return None
 
+    @torch.no_grad()
+    def predict_step(self, batch, batch_idx=0, dataloader_idx=None):
+        """Grid inference of one subject (src/model.py:314-333): ``batch`` is the reference's
+        ``(sampler, i_agg, t_agg, o_agg)`` with the device-side ``inference.GridSampler`` /
+        ``GridAggregator``; the patch loop, ``unpack_batch(test=True)`` and the three ``add_batch`` calls
+        are the reference's.  Returns all three aggregated volumes named by content -- the reference
+        returns the one it calls ``pred_tensor``, which is the aggregated INPUT (``o_agg`` gets ``x``).
+        Metrics and NIfTI saving (:327-331) stay with the caller."""
+        from .inference import LOCATION, GridPrediction
+        sampler, i_agg, t_agg, o_agg = batch
+        for patch_batch in sampler.batches(self.batch_size):
+            x, y = self.unpack_batch(patch_batch, test=True)
+            loc = patch_batch[LOCATION]
+            y_hat = self(x)
+            i_agg.add_batch(y_hat, loc)
+            t_agg.add_batch(y, loc)
+            o_agg.add_batch(x, loc)
+        return GridPrediction(i_agg.get_output_tensor(), t_agg.get_output_tensor(), o_agg.get_output_tensor())
+
     def stacked_logs(self) -> torch.Tensor:
         """The step's scalars as ONE tensor (order: LOG_KEYS) -- a single all-reduce replaces the
         reference's six ``sync_dist`` logs."""
