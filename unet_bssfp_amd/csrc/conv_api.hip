@@ -1,4 +1,5 @@
 // Host dispatch of the implicit-GEMM convolution kernels (C ABI: mi355_conv_fwd).
+#include <stdlib.h>
 #include "conv_kernels.h"
 
 namespace {
@@ -20,7 +21,15 @@ int gcd_i(long long a, long long b) { while (b) { long long t = a % b; a = b; b 
 // 0 wide (2x4x32, 2 subtiles/wave)  1 mid (2x8x16, 2)  2 small (4x8x8, 2)
 // 3 wide4 (4x4x32, 4: bf16 thin-Cout layers)  4 mid1 (2x4x16, 1)  5 small1 (2x8x8, 1): more workgroups at the low levels
 // 6 wide8 (4x4x32, 8 waves x 2 subtiles: 25 % less halo traffic than 2x4x32 at the same occupancy)
-const int kTD[7] = {2, 2, 4, 4, 2, 2, 4}, kTH[7] = {4, 8, 8, 4, 4, 8, 4}, kTW[7] = {32, 16, 8, 32, 16, 8, 32}, kVT[7] = {2, 2, 2, 4, 1, 1, 2};
+// 7, 8: retired experiments (row reuse inside conv_halo_kernel with register staging: 216 VGPRs or spills, slower)
+// 9 ru (4x4x32, 4 waves, row-reuse loop, halo by LDS-DMA: conv_ru_kernel)
+const int kTD[10] = {2, 2, 4, 4, 2, 2, 4, 8, 4, 4}, kTH[10] = {4, 8, 8, 4, 4, 8, 4, 4, 4, 4}, kTW[10] = {32, 16, 8, 32, 16, 8, 32, 32, 32, 32},
+          kVT[10] = {2, 2, 2, 4, 1, 1, 2, 4, 4, 4};
+
+int forced_shape() {      // A/B knob: MI355_CONV_SHAPE=<6|9> overrides the wide bf16 3x3x3 choice
+  static const int v = [] { const char* e = getenv("MI355_CONV_SHAPE"); return e ? atoi(e) : -1; }();
+  return v;
+}
 
 int make_plan(const mi355_conv_desc* d, Plan* p) {
   MI355_REQUIRE(d && d->x0 && d->wp && d->y, "conv: null pointer");
@@ -54,7 +63,14 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
     };
     if (p->shape == 0) {
       // thin-Cout full-resolution layers in bf16: 4 voxel subtiles per weight fragment (halves L1 weight traffic)
-      if (d->dtype == MI355_DT_BF16 && d->ks == 3 && count(6, p->ct) >= 1024) p->shape = 6;
+      if (d->dtype == MI355_DT_BF16 && d->ks == 3 && count(6, p->ct) >= 1024) {
+        p->shape = p->ct == 1 ? 9 : 6;             // thin Cout: row-reuse + LDS-DMA kernel
+        const int f = forced_shape();
+        if (f == 6 || f == 9) p->shape = f;
+        // the LDS-DMA kernel addresses its inputs with 32-bit byte offsets
+        const long long nv = (long long)d->n * d->di * d->hi * d->wi;
+        if (p->shape == 9 && (nv * d->ld0 * 2 >= (1ll << 31) || nv * (d->c1 ? d->ld1 : 0) * 2 >= (1ll << 31))) p->shape = 6;
+      }
     } else {
       // low levels: few tiles -> favour more, smaller workgroups (the K loop is long, the grid is not)
       if (count(p->shape, p->ct) < 512) p->ct = 1;
@@ -126,6 +142,10 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
   a.cls_cout = d->cls_cout;
   a.nbias = d->nbias > 0 ? d->nbias : d->coutp;
   a.kslab = (float*)d->workspace;
+  {
+    static const int abl = [] { const char* e = getenv("MI355_CONV_ABLATE"); return e ? atoi(e) : 0; }();
+    a.ablate = abl;
+  }
   if (p.ksplit > 1) {
     const long long need = (long long)p.ksplit * a.m_total * d->coutp * 4;
     MI355_REQUIRE(d->workspace && d->workspace_bytes >= need, "conv: split-K workspace too small (%lld < %lld)",
@@ -160,6 +180,11 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
           constexpr int lds = conv_halo_lds<T, 3, 4, 4, 32, 2, 8>();
           if (p.ct == 2) conv_halo_kernel<T, 3, 4, 4, 32, 2, 8><<<grid, block, lds, st>>>(a);
           else conv_halo_kernel<T, 3, 4, 4, 32, 1, 8><<<grid, block, lds, st>>>(a);
+        }
+      } else if (p.shape == 9) {
+        if constexpr (sizeof(T) == 2) {
+          if (p.ct == 2) conv_ru_kernel<2><<<grid, block, kRuLds, st>>>(a);
+          else conv_ru_kernel<1><<<grid, block, kRuLds, st>>>(a);
         }
       } else { HALO_KS(3) }
     } else { HALO_KS(2) }

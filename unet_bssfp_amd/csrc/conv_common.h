@@ -21,6 +21,7 @@ struct ConvArgs {
   float* kslab;                    // [ksplit][n*do*ho*wo][coutp] f32 partial sums
   int cls_cout;                    // gather kernel: transposed-conv classes folded into the cout index (0 = off)
   int nbias;                       // entries of bias
+  int ablate;                      // timing-only diagnostics (MI355_CONV_ABLATE): 1 no halo loads, 2 no output stores, 4 no weight loads
 };
 
 // Epilogue shared by both kernels.
@@ -149,7 +150,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, f32x16 (&a
           const int v = pass * 16 + (lane >> 2);
           const int rh = v / TW, cw = v % TW;
           const uint4 val = *reinterpret_cast<const uint4*>(wbuf + v * 64 + (lane & 3) * 16);
-          if (to.dvalid[vt] && rh < to.hleft[vt] && cw < to.wleft[vt] && co0 + 8 <= a.cstore)
+          if (to.dvalid[vt] && rh < to.hleft[vt] && cw < to.wleft[vt] && co0 + 8 <= a.cstore && !(a.ablate & 2))
             *reinterpret_cast<uint4*>(reinterpret_cast<T*>(a.y) + to.base[vt] + rh * to.hstride + cw * to.wstride + co0) = val;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the patch is overwritten

@@ -348,3 +348,158 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvArgs a) {
   }
   conv_epilogue<T, VT, CT>(a, acc, yoff, co_base, blockIdx.x, red, co_store);
 }
+
+// ------------------------------------------------------------------------------------------
+// conv_ru_kernel: bf16 3x3x3 stride-1 convolution for the wide (full-resolution) layers.
+//   tile 4(d) x 4(h) x 32(w), 4 waves, wave = one d-slice of 4 rows ("row reuse": the A fragment of halo
+//   row (d + kd, hy, kw) feeds every (row, kh) with row + kh = hy, and a weight fragment feeds the 4 rows:
+//   54 LDS reads + 27 weight reads per 108 MFMAs per wave and chunk, instead of 108 + 54 -- with 32 output
+//   channels per workgroup every fragment has ONE MFMA to feed, so the plain loop is bound by those reads).
+//   The halo goes global -> LDS directly (`buffer_load_dwordx4 ... lds`, out-of-range = zero padding): no
+//   staging registers, no ds_write pass; image = 2 planes (channels 0-7 / 8-15) of 16 B per voxel, a lane
+//   half reads one plane with consecutive voxels 16 B apart (conflict-free without padding: measured 0
+//   bank conflicts).  40 KB of LDS and <= 128 VGPRs: 4 workgroups per CU, whose load / MFMA / store phases
+//   overlap each other.
+// ------------------------------------------------------------------------------------------
+constexpr int kRuVox = 6 * 6 * 34;                    // halo voxels
+constexpr int kRuBlocks = (kRuVox + 63) / 64;         // 64-voxel wave-instructions per plane
+constexpr int kRuPlane = kRuBlocks * 1024;
+constexpr int kRuLds = 2 * kRuPlane;
+
+template <int CT>
+__global__ __launch_bounds__(256, CT == 1 ? 4 : 2) void conv_ru_kernel(const ConvArgs a) {
+  using T = bf16_t;
+  constexpr int TD = 4, TH = 4, TW = 32, NW = 4, VT = 4, HH = 6, HW = 34;
+  constexpr int NI = (2 * kRuBlocks + NW - 1) / NW;   // LDS-DMA instructions per wave and chunk
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int co_base = blockIdx.y * (32 * CT);
+  int tile;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;
+  }
+  // tile id -> tile coordinates.  The ~128 workgroups an XCD runs at a time (32 CUs x 4) should form a compact
+  // 3-D block, so that the halo planes neighbouring tiles share are requested close together in time:
+  // blocks of 8 (d) x 4 (h) x all (w) tiles, d-blocks fastest (-4 % on 96->32 at 128^3 against w-h-d order,
+  // which runs one whole 4-plane d-layer at a time).
+  int tw_i, th_i, td_i, tn;
+  {
+    constexpr int BD = 8, BH = 4;
+    const int per = a.tiles_d * a.tiles_h * a.tiles_w;
+    tn = tile / per;
+    int t = tile - tn * per;
+    if ((a.tiles_d % BD) == 0 && (a.tiles_h % BH) == 0) {
+      const int bs = BD * BH * a.tiles_w, b = t / bs, in = t - b * bs, ndg = a.tiles_d / BD;
+      tw_i = in % a.tiles_w;
+      th_i = (b / ndg) * BH + (in / a.tiles_w) % BH;
+      td_i = (b % ndg) * BD + in / (a.tiles_w * BH);
+    } else {
+      tw_i = t % a.tiles_w; t /= a.tiles_w;
+      th_i = t % a.tiles_h;
+      td_i = t / a.tiles_h;
+    }
+  }
+  const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
+
+  // this lane's source voxel for each of the wave's LDS-DMA instructions (instruction id = i * NW + wave:
+  // plane = id & 1, 64-voxel block = id >> 1), -1 = zero padding / beyond the halo
+  int gvox[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int id = i * NW + wave, v = (id >> 1) * 64 + lane;
+    const int hd = v / (HH * HW), hh = (v / HW) % HH, hw = v % HW;
+    const int gd = d0 + hd - a.pd, gh = h0 + hh - a.ph, gw = w0 + hw - a.pw;
+    const bool ok = id < 2 * kRuBlocks && v < kRuVox && gd >= 0 && gd < a.di && gh >= 0 && gh < a.hi && gw >= 0 && gw < a.wi;
+    gvox[i] = ok ? ((tn * a.di + gd) * a.hi + gh) * a.wi + gw : -1;
+  }
+  const long long nvox = (long long)a.n * a.di * a.hi * a.wi;
+  const auto rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x0, 0, (int)(((nvox - 1) * a.ld0 + a.c0) * 2), 0x00020000);
+  const auto rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.c1 ? a.x1 : a.x0), 0,
+                                                     a.c1 ? (int)(((nvox - 1) * a.ld1 + a.c1) * 2) : 0, 0x00020000);
+
+  const int lbase = (wave * HH * HW + r) * 16 + h * kRuPlane;
+  const char* wlane = a.wp + ((long long)co_base + r) * 32 + h * 16;
+  const long long wtap = (long long)a.coutp * 32;
+
+  f32x16 acc[VT][CT];
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[vt][ct][i] = 0.f;
+
+  for (int c = 0; c < a.nchunks; ++c) {
+    const int cb = c * 16;
+    const bool first = cb < a.c0;
+    const int ld2 = (first ? a.ld0 : a.ld1) * 2;
+    const int coff = (first ? cb : cb - a.c0) * 2 + (wave & 1) * 16;
+    if (c) __syncthreads();                     // the previous chunk's LDS reads are done
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int id = i * NW + wave;
+      if (id < 2 * kRuBlocks && !(a.ablate & 1)) {   // wave-uniform
+        const int off = gvox[i] >= 0 ? gvox[i] * ld2 + coff : (int)0x80000000;   // out of range -> zeros land in LDS
+        lds_ptr dst = (lds_ptr)(smem + (id & 1) * kRuPlane + (id >> 1) * 1024);
+        if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, off, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, off, 0, 0, 0);
+      }
+    }
+    __syncthreads();                            // hipcc drains vmcnt(0) in front of the barrier
+    const char* wc = wlane + (long long)c * 27 * wtap;
+    // 9 (kd, kw) steps, NOT unrolled (a fully unrolled body makes hipcc hoist every load and spill);
+    // the next step's three weight fragments are fetched while this step's 12 MFMAs run
+    Frag<T> bn[3][CT];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) bn[kh][ct].load(wc + (kh * 3) * wtap + ct * 1024);
+#pragma unroll 1
+    for (int it = 0; it < 9; ++it) {
+      const int kd = it / 3, kw = it - kd * 3;
+      Frag<T> b[3][CT];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) b[kh][ct] = bn[kh][ct];
+      if (it < 8 && !(a.ablate & 4)) {
+        const int nd = (it + 1) / 3, nw = (it + 1) - nd * 3;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) bn[kh][ct].load(wc + (nd * 9 + kh * 3 + nw) * wtap + ct * 1024);
+      }
+      const char* ap = smem + lbase + (kd * HH * HW + kw) * 16;
+#pragma unroll
+      for (int hy = 0; hy < TH + 2; ++hy) {
+        Frag<T> af;
+        af.load(ap + hy * HW * 16);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int row = hy - kh;
+          if (row >= 0 && row < TH) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) mma16(af, b[kh][ct], acc[row][ct]);
+          }
+        }
+      }
+    }
+  }
+
+  TileOut<VT> to;
+  to.hstride = (long long)a.os * a.wy * a.ldy;
+  to.wstride = (long long)a.os * a.ldy;
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt) {
+    const int gd = d0 + wave, gh = h0 + vt, gw = w0;
+    to.base[vt] = ((((long long)tn * a.dy + (gd * a.os + a.od)) * a.hy + (gh * a.os + a.oh)) * a.wy + (gw * a.os + a.ow)) * a.ldy;
+    to.dvalid[vt] = gd < a.do_;
+    to.hleft[vt] = a.ho - gh;
+    to.wleft[vt] = a.wo - gw;
+  }
+  conv_epilogue_tile<T, VT, CT, TW, NW>(a, acc, to, co_base, tile, reinterpret_cast<float*>(smem));
+}
