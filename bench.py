@@ -37,7 +37,7 @@ import torch.distributed as dist  # noqa: E402
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 # dominant kernel family = full-resolution 3x3x3 implicit GEMM with 32 output channels
 # plan id = 10000*ks + 1000*halo + 100*tile_shape + 10*voxel_subtiles_per_wave + cout_subtiles_per_wave
-DOMINANT_PLAN = {"bf16": (31621, "conv_halo_kernel<bf16_t,3,4,4,32,1,8>"), "f32": (31021, "conv_halo_kernel<float,3,2,4,32,1>")}
+DOMINANT_PLAN = {"bf16": (31941, "conv_ru_kernel<1>"), "f32": (31021, "conv_halo_kernel<float,3,2,4,32,1>")}
 
 
 def parse():

@@ -26,7 +26,7 @@ int gcd_i(long long a, long long b) { while (b) { long long t = a % b; a = b; b 
 const int kTD[10] = {2, 2, 4, 4, 2, 2, 4, 8, 4, 4}, kTH[10] = {4, 8, 8, 4, 4, 8, 4, 4, 4, 4}, kTW[10] = {32, 16, 8, 32, 16, 8, 32, 32, 32, 32},
           kVT[10] = {2, 2, 2, 4, 1, 1, 2, 4, 4, 4};
 
-int forced_shape() {      // A/B knob: MI355_CONV_SHAPE=<6|9> overrides the wide bf16 3x3x3 choice
+int forced_shape() {      // A/B knob, see make_plan
   static const int v = [] { const char* e = getenv("MI355_CONV_SHAPE"); return e ? atoi(e) : -1; }();
   return v;
 }
@@ -62,14 +62,20 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
              (d->coutp / (32 * ct));
     };
     if (p->shape == 0) {
-      // thin-Cout full-resolution layers in bf16: 4 voxel subtiles per weight fragment (halves L1 weight traffic)
-      if (d->dtype == MI355_DT_BF16 && d->ks == 3 && count(6, p->ct) >= 1024) {
-        p->shape = p->ct == 1 ? 9 : 6;             // thin Cout: row-reuse + LDS-DMA kernel
+      if (d->dtype == MI355_DT_BF16 && d->ks == 3) {
+        // wide bf16 3x3x3 layers: the row-reuse + LDS-DMA kernel (shape 9) when its 4x4x32 tiles fill the chip,
+        // else 8-wave 4x4x32 tiles (shape 6) / the plain 2x4x32 tile.  MI355_CONV_SHAPE=<0|6|9> forces a choice (A/B).
         const int f = forced_shape();
-        if (f == 6 || f == 9) p->shape = f;
-        // the LDS-DMA kernel addresses its inputs with 32-bit byte offsets
         const long long nv = (long long)d->n * d->di * d->hi * d->wi;
-        if (p->shape == 9 && (nv * d->ld0 * 2 >= (1ll << 31) || nv * (d->c1 ? d->ld1 : 0) * 2 >= (1ll << 31))) p->shape = 6;
+        const bool ru_ok = nv * d->ld0 * 2 < (1ll << 31) && nv * (d->c1 ? d->ld1 : 0) * 2 < (1ll << 31);   // 32-bit byte offsets
+        const bool big = count(6, p->ct) >= 1024;
+        const long long c9 = count(9, p->ct);
+        int pick = (p->ct == 1 ? c9 >= 1024 : c9 >= 512) ? 9 : (big ? 6 : 0);
+        if (f == 0) pick = 0;
+        else if (f == 6) pick = big ? 6 : 0;
+        else if (f == 9) pick = 9;
+        if (pick == 9 && !ru_ok) pick = big ? 6 : 0;
+        p->shape = pick;
       }
     } else {
       // low levels: few tiles -> favour more, smaller workgroups (the K loop is long, the grid is not)
