@@ -113,26 +113,29 @@ struct WreduceArgs {
   int co_cls;            // >0: co index is blk*co_cls + co, blk selects the destination tap
 };
 
-// 256 threads = 32 float4 groups (128 consecutive elements, 512 B per slab row) x 8 slab lanes;
-// 4 independent 16-B loads in flight per thread, fixed-order LDS combine (deterministic)
+// 256 threads = 16 float4 groups (64 consecutive elements, 256 B per slab row) x 16 slab lanes;
+// 8 independent 16-B loads in flight per thread, fixed-order LDS combine (deterministic).  The slabs of one
+// layer always add up to ~57 MB (splits x taps x cin x cout), so this kernel is a pure HBM stream: enough
+// blocks (>= 432) and bytes in flight per CU to pull it at bandwidth.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WreduceArgs a) {
-  __shared__ float4 red[8][32];
+  __shared__ float4 red[16][16];
   const long long per = (long long)a.ntaps * a.cinp * a.coutp;        // multiple of 1024
-  const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const long long idx = ((long long)blockIdx.x * 32 + e) * 4;
+  const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long long idx = ((long long)blockIdx.x * 16 + e) * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (idx < per) {
     const float* base = a.slab + idx;
     int k = sl;
-    for (; k + 24 < a.nslabs; k += 32) {
-      const float4 v0 = *reinterpret_cast<const float4*>(base + (long long)k * per);
-      const float4 v1 = *reinterpret_cast<const float4*>(base + (long long)(k + 8) * per);
-      const float4 v2 = *reinterpret_cast<const float4*>(base + (long long)(k + 16) * per);
-      const float4 v3 = *reinterpret_cast<const float4*>(base + (long long)(k + 24) * per);
-      s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
-      s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+    for (; k + 112 < a.nslabs; k += 128) {
+      float4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(base + (long long)(k + 16 * j) * per);
+      s.x += ((v[0].x + v[1].x) + (v[2].x + v[3].x)) + ((v[4].x + v[5].x) + (v[6].x + v[7].x));
+      s.y += ((v[0].y + v[1].y) + (v[2].y + v[3].y)) + ((v[4].y + v[5].y) + (v[6].y + v[7].y));
+      s.z += ((v[0].z + v[1].z) + (v[2].z + v[3].z)) + ((v[4].z + v[5].z) + (v[6].z + v[7].z));
+      s.w += ((v[0].w + v[1].w) + (v[2].w + v[3].w)) + ((v[4].w + v[5].w) + (v[6].w + v[7].w));
     }
-    for (; k < a.nslabs; k += 8) {
+    for (; k < a.nslabs; k += 16) {
       const float4 v = *reinterpret_cast<const float4*>(base + (long long)k * per);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WreduceArgs a) 
   __syncthreads();
   if (sl != 0 || idx >= per) return;
 #pragma unroll
-  for (int q = 1; q < 8; ++q) {
+  for (int q = 1; q < 16; ++q) {
     const float4 v = red[q][e];
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
@@ -163,6 +166,45 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WreduceArgs a) 
   }
 }
 
+
+// Few slabs, many weights (the 8^3 / 16^3 levels: 2-16 slabs of up to 28 MB): the cost is the WRITE side --
+// consecutive slab elements are consecutive output channels, 27*cin floats apart in dw[co][ci][taps], so the
+// kernel above scatters 4-byte stores (measured 176 us for 512->512).  Here a block owns all taps of an
+// 8 (ci) x 32 (co) patch, sums the slabs in order (128-B read segments) and turns the patch through LDS so
+// that every output-channel row is written as one contiguous run of 8 * taps floats.
+template <int NT>
+__global__ __launch_bounds__(256) void wgrad_reduce_dense_kernel(const WreduceArgs a) {
+  constexpr int ROW = 8 * NT + 1;
+  __shared__ float tile[32 * ROW];
+  const int t = threadIdx.x, co_l = t & 31, ci_l = t >> 5;
+  const int ci0 = blockIdx.x * 8, co0 = blockIdx.y * 32;
+  const long long per = (long long)NT * a.cinp * a.coutp;
+  const float* base = a.slab + ((long long)(ci0 + ci_l)) * a.coutp + co0 + co_l;
+  const long long tstride = (long long)a.cinp * a.coutp;
+  float s[NT];
+#pragma unroll
+  for (int tap = 0; tap < NT; ++tap) s[tap] = 0.f;
+  for (int k = 0; k < a.nslabs; ++k) {            // slab order fixed => deterministic; NT loads in flight per lane
+    const float* p = base + (long long)k * per;
+#pragma unroll
+    for (int tap = 0; tap < NT; ++tap) s[tap] += p[tap * tstride];
+  }
+#pragma unroll
+  for (int tap = 0; tap < NT; ++tap) tile[co_l * ROW + ci_l * NT + tap] = s[tap];
+  __syncthreads();
+  const int nci = min(8, a.cin - ci0);            // valid input channels of this patch
+  if (nci <= 0) return;
+  const int run = nci * NT;
+  for (int r = 0; r < 32; ++r) {
+    const int co = co0 + r;
+    if (co >= a.cout) break;
+    float* dst = a.dw + (long long)co * a.s_co + (long long)ci0 * a.s_ci;
+    for (int j = t; j < run; j += 256) {
+      const float v = tile[r * ROW + j];
+      if (a.accumulate) dst[j] += v; else dst[j] = v;
+    }
+  }
+}
 
 // ------------------------------------------------------------------------------------------
 // bf16 3x3x3 stride-1 weight gradient on v_mfma_f32_32x32x16_bf16.
@@ -422,6 +464,15 @@ extern "C" int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream) {
   q.s2d_cp = d->s2d_cp;
   q.co_cls = d->g_cls_cout;
   const long long per = (long long)q.ntaps * q.cinp * q.coutp;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 127) / 128)), dim3(256), 0, st, q);
+  const int k3 = d->ks * d->ks * d->ks;
+  const bool dense = !q.s2d_cp && !q.co_cls && q.s_k2 == 1 && q.s_k1 == d->ks && q.s_k0 == d->ks * d->ks && q.s_ci == k3 &&
+                     q.tb0 == 0 && q.tb1 == 0 && q.tb2 == 0 && q.ts0 == 1 && q.ts1 == 1 && q.ts2 == 1;
+  if (dense && q.nslabs <= 16 && (d->ks == 3 || d->ks == 1) && q.cinp % 8 == 0 && q.coutp % 32 == 0) {
+    const dim3 grid((unsigned)(q.cinp / 8), (unsigned)(q.coutp / 32));
+    if (d->ks == 3) wgrad_reduce_dense_kernel<27><<<grid, dim3(256), 0, st>>>(q);
+    else wgrad_reduce_dense_kernel<1><<<grid, dim3(256), 0, st>>>(q);
+    return mi355_check_launch("wgrad_reduce_dense");
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, st, q);
   return mi355_check_launch("wgrad_reduce");
 }
