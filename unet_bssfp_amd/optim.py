@@ -95,6 +95,26 @@ class FusedAdamW(torch.optim.Optimizer):
                                                      torch.cuda.current_stream().cuda_stream), "adamw_multi")
         return loss
 
+    def load_state_dict(self, state_dict):
+        """torch's AdamW keeps ``step`` as a tensor; here it is a Python int mirrored by a device counter."""
+        super().load_state_dict(state_dict)
+        self._step_dev.clear()
+        self._calls.clear()
+        for gi, group in enumerate(self.param_groups):
+            steps = set()
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st:
+                    st["step"] = int(st["step"].item()) if isinstance(st["step"], torch.Tensor) else int(st["step"])
+                    steps.add(st["step"])
+                    for k in ("exp_avg", "exp_avg_sq"):
+                        st[k] = st[k].to(device=p.device, dtype=torch.float32).contiguous()
+            if len(steps) == 1 and next(iter(steps)) > 0:
+                t = next(iter(steps))
+                dev = next(p.device for p in group["params"])
+                self._step_dev[gi] = torch.full((1,), t, dtype=torch.int64, device=dev)
+                self._calls[gi] = t
+
     def sync_step_counts(self):
         """Refresh the Python-side ``state['step']`` from the device counters (after graph replays)."""
         for gi, group in enumerate(self.param_groups):
