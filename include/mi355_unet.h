@@ -303,6 +303,23 @@ int mi355_patch_aggregate(const float* patches, const int32_t* locs9, int32_t np
                           int32_t w, void* stream);
 int mi355_patch_average_finalize(float* vol, const float* count, int32_t c, int64_t voxels, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Validation metrics -- MONAI's MAEMetric / PSNRMetric(1) /
+ * SSIMMetric(3, data_range=1) as used by `compute_metrics` (src/model.py:158-160, 215-220).
+ * f32 NCDHW inputs; one result per batch item.
+ *   err_sums: out[item] = {sum |a-b|, sum (a-b)^2} over per_item elements (f64);
+ *             partials >= items * mi355_err_blocks(per_item) * 2 doubles.
+ *   ssim3d  : Gaussian window (`window` = HOST array of `win` <= 15 normalised 1-D weights), "valid"
+ *             windows, out[item] = mean SSIM over channels and window positions (f64).
+ * ---------------------------------------------------------------------------------------- */
+int32_t mi355_err_blocks(int64_t per_item);
+int mi355_err_sums(const float* a, const float* b, int64_t per_item, int32_t items, double* partials,
+                   double* out, void* stream);
+int64_t mi355_ssim3d_workspace_bytes(int32_t items, int32_t c, int32_t d, int32_t h, int32_t w, int32_t win);
+int mi355_ssim3d(const float* x, const float* y, int32_t items, int32_t c, int32_t d, int32_t h, int32_t w,
+                 int32_t win, const float* window, float c1, float c2, void* workspace,
+                 int64_t workspace_bytes, double* out, void* stream);
+
 /* layout probe used by the tests: writes lane -> (row, col) maps of the MFMA accumulators */
 int mi355_mfma_selftest(float* out_f32_1024, float* out_bf16_1024, void* stream);
 

@@ -90,6 +90,10 @@ _SIGNATURES = {
     "mi355_patch_gather": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mi355_patch_aggregate": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mi355_patch_average_finalize": (C.c_int, [_vp, _vp, _i32, _i64, _vp]),
+    "mi355_err_blocks": (_i32, [_i64]),
+    "mi355_err_sums": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "mi355_ssim3d_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32, _i32]),
+    "mi355_ssim3d": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _f32, _f32, _vp, _i64, _vp, _vp]),
     "mi355_mfma_selftest": (C.c_int, [_vp, _vp, _vp]),
 }
 

@@ -167,6 +167,29 @@ class bSSFPToDWITensorModel(nn.Module):
         self.last_logs = logs
         return None
 
+    def compute_metrics(self, y_hat, y, step_name, logs=None):
+        """``self.log(f'{step_name}_metric_{name}', metric_fn(y_hat, y).mean())`` for every entry of
+        ``metric_fns`` (src/model.py:215-220).  Default list: PSNR(1), SSIM(3-D, data_range 1), L1 on the
+        device (``metrics.reference_metric_fns``); the reference's FID entry needs remote weights."""
+        if getattr(self, "metric_fns", None) is None:
+            from .metrics import reference_metric_fns
+            self.metric_fns = reference_metric_fns()
+        logs = self.last_logs if logs is None else logs
+        for metric_fn, name in self.metric_fns:
+            logs[f"{step_name}_metric_{name}"] = metric_fn(y_hat, y).mean()
+        return logs
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx=0):
+        """src/model.py:283-289: generator step without an update, ``val_loss`` and the metrics."""
+        logs: Dict[str, torch.Tensor] = {}
+        x, y = self.unpack_batch(batch)
+        loss, y_hat = self._gen_step(x, y, logs, "val")
+        logs["val_loss"] = loss.detach()
+        self.compute_metrics(y_hat, y, "val", logs)
+        self.last_logs = logs
+        return loss
+
     @torch.no_grad()
     def predict_step(self, batch, batch_idx=0, dataloader_idx=None):
         """Grid inference of one subject (src/model.py:314-333): ``batch`` is the reference's
