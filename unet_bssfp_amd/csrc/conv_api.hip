@@ -26,6 +26,12 @@ int gcd_i(long long a, long long b) { while (b) { long long t = a % b; a = b; b 
 const int kTD[10] = {2, 2, 4, 4, 2, 2, 4, 8, 4, 4}, kTH[10] = {4, 8, 8, 4, 4, 8, 4, 4, 4, 4}, kTW[10] = {32, 16, 8, 32, 16, 8, 32, 32, 32, 32},
           kVT[10] = {2, 2, 2, 4, 1, 1, 2, 4, 4, 4};
 
+int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+// plan experiments (A/B in one process each): MI355_CONV_CT=<1|2> forces the Cout tiles per workgroup of halo plans,
+// MI355_CONV_KSPLIT=<n> forces the split-K factor (1 = off) where a split is legal
+int forced_ct() { static const int v = env_int("MI355_CONV_CT", 0); return v; }
+int forced_ksplit() { static const int v = env_int("MI355_CONV_KSPLIT", 0); return v; }
+
 int forced_shape() {      // A/B knob, see make_plan
   static const int v = [] { const char* e = getenv("MI355_CONV_SHAPE"); return e ? atoi(e) : -1; }();
   return v;
@@ -56,6 +62,7 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
   p->ct = (d->coutp % 64 == 0) ? 2 : 1;
   p->halo = ((d->ks == 3 || d->ks == 2) && d->stride == 1);
   if (p->halo) {
+    if (forced_ct() == 1) p->ct = 1;
     p->shape = d->wo > 16 ? 0 : (d->wo > 8 ? 1 : 2);
     auto count = [&](int sh, int ct) {
       return (long long)ceil_div(d->do_, kTD[sh]) * ceil_div(d->ho, kTH[sh]) * ceil_div(d->wo, kTW[sh]) * d->n *
@@ -77,6 +84,9 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
         if (pick == 9 && !ru_ok) pick = big ? 6 : 0;
         p->shape = pick;
       }
+      // 32^3-level layers on the plain tile: one 64-channel tile per workgroup leaves <= 1 workgroup per CU on a
+      // long K loop; 32-channel tiles double the workgroups (measured 128->64: 40 -> 30 us, 128->128: 48 -> 41 us)
+      if (p->shape == 0 && p->ct == 2 && count(0, 2) < 512) p->ct = 1;
     } else {
       // low levels: few tiles -> favour more, smaller workgroups (the K loop is long, the grid is not)
       if (count(p->shape, p->ct) < 512) p->ct = 1;
@@ -107,8 +117,10 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
     // group => split the contraction over blockIdx.z and combine in a second kernel
     const long long wgs = p->tiles * (d->coutp / (32 * p->ct));
     const int nchunks = (d->c0 + d->c1) / 16;
-    if ((wgs < 256 && nchunks >= 8) || (wgs < 512 && nchunks >= 16)) {   // (32^3 x 128 ch measured slower split)
+    const int fk = forced_ksplit();
+    if ((fk == 0 && ((wgs < 256 && nchunks >= 8) || (wgs < 512 && nchunks >= 16))) || fk > 1) {   // (32^3 x 128 ch measured slower split)
       long long ks = (1024 + wgs - 1) / wgs;
+      if (fk > 1) ks = fk;
       if (ks > nchunks / 2) ks = nchunks / 2;
       if (ks > 32) ks = 32;
       if (ks >= 2) {
