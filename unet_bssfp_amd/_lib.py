@@ -9,7 +9,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355_unet.so")
+# MI355_LIB: load another build of the same ABI (A/B runs of two kernel versions inside one gpurun call)
+LIB_PATH = os.environ.get("MI355_LIB") or os.path.join(_HERE, "libmi355_unet.so")
 
 DT_F32 = 0
 DT_BF16 = 1

@@ -86,7 +86,7 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
       }
       // 32^3-level layers on the plain tile: one 64-channel tile per workgroup leaves <= 1 workgroup per CU on a
       // long K loop; 32-channel tiles double the workgroups (measured 128->64: 40 -> 30 us, 128->128: 48 -> 41 us)
-      if (p->shape == 0 && p->ct == 2 && count(0, 2) < 512) p->ct = 1;
+      if (p->shape == 0 && p->ct == 2 && count(0, 2) < 512 && forced_ct() != 2) p->ct = 1;
     } else {
       // low levels: few tiles -> favour more, smaller workgroups (the K loop is long, the grid is not)
       if (count(p->shape, p->ct) < 512) p->ct = 1;
