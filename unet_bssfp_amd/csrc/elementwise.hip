@@ -245,11 +245,24 @@ __device__ __forceinline__ unsigned long long eff_seed(unsigned long long salt, 
 }
 // keep-mask of element `idx` (logical index, independent of ld): 16 bits per element, one 64-bit mix per
 // aligned group of 4 elements (the compiler shares it across the 4 / 8 elements of a 16-byte piece)
-__device__ __forceinline__ bool drop_keep(unsigned long long seed, unsigned long long idx, unsigned thr16) {
-  unsigned long long x = (idx >> 2) * 0x9E3779B97F4A7C15ull + seed;
+__device__ __forceinline__ unsigned long long drop_group_bits(unsigned long long seed, unsigned long long group) {
+  unsigned long long x = group * 0x9E3779B97F4A7C15ull + seed;
   x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull; x ^= x >> 32;
-  const unsigned bits = (unsigned)(x >> (16 * (idx & 3))) & 0xffffu;
-  return bits >= thr16;
+  return x;
+}
+// keep-masks of the EPV (4 or 8) elements of one 16-byte piece starting at logical index e0 (a multiple of 4:
+// channel counts are multiples of 16).  The mixes are computed explicitly once per group of 4 -- hipcc cannot
+// prove the alignment of e0 and would otherwise mix once per element.
+template <int EPV>
+__device__ __forceinline__ unsigned drop_keep_mask(unsigned long long seed, unsigned long long e0, unsigned thr16) {
+  unsigned m = 0;
+#pragma unroll
+  for (int g4 = 0; g4 < EPV / 4; ++g4) {
+    const unsigned long long x = drop_group_bits(seed, (e0 >> 2) + g4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m |= ((((unsigned)(x >> (16 * k))) & 0xffffu) >= thr16 ? 1u : 0u) << (4 * g4 + k);
+  }
+  return m;
 }
 
 struct NormActArgs {
@@ -264,7 +277,7 @@ struct NormActArgs {
   S2D s2d_da;     // backward: read `da` from a space-to-depth tensor
 };
 
-template <typename T>
+template <typename T, bool DROP>
 __global__ __launch_bounds__(256) void normact_fwd_kernel(const NormActArgs q) {
   constexpr int EPV = Elem<T>::kPer16B;
   const int g = blockIdx.y;
@@ -272,7 +285,7 @@ __global__ __launch_bounds__(256) void normact_fwd_kernel(const NormActArgs q) {
   const int piece = threadIdx.x % lpr, rsub = threadIdx.x / lpr;
   if (rsub >= rpp) return;
   const int ch0 = piece * EPV;
-  const unsigned long long seed = q.thr16 ? eff_seed(q.seed, q.seed_ptr) : 0ull;
+  const unsigned long long seed = DROP ? eff_seed(q.seed, q.seed_ptr) : 0ull;
   float sc[EPV], sh[EPV];
 #pragma unroll
   for (int j = 0; j < EPV; ++j) {
@@ -291,10 +304,12 @@ __global__ __launch_bounds__(256) void normact_fwd_kernel(const NormActArgs q) {
     Vec16<T> v;
     v.load(zb + row * q.ldz + ch0);
     const unsigned long long e0 = ((unsigned long long)g * q.rows_per_group + row) * q.c + ch0;
+    unsigned keep = 0;
+    if constexpr (DROP) keep = drop_keep_mask<EPV>(seed, e0, q.thr16);
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
       float t = v.f[j] * sc[j] + sh[j];
-      if (q.thr16) t = drop_keep(seed, e0 + j, q.thr16) ? t * q.drop_scale : 0.f;
+      if constexpr (DROP) t = (keep >> j) & 1u ? t * q.drop_scale : 0.f;
       v.f[j] = t > 0.f ? t : t * q.slope;
     }
     if (q.s2d_a.d) v.store(reinterpret_cast<T*>(q.a) + s2d_offset(q.s2d_a, (long long)g * q.rows_per_group + row, q.lda) + ch0);
@@ -316,21 +331,20 @@ __device__ __forceinline__ void load_bwd_const(const NormActArgs& q, int g, int 
   }
 }
 // g = da * dropout * lrelu'(pre);  xhat = (z - mean) * rstd  (xhat = z when there is no norm)
-__device__ __forceinline__ void bwd_elem(const NormActArgs& q, unsigned long long seed, float mu, float rs, float ga,
-                                         float be, float zv, float dav, unsigned long long eidx, float& gout,
-                                         float& xhat) {
+template <bool DROP>
+__device__ __forceinline__ void bwd_elem(const NormActArgs& q, bool keep, float mu, float rs, float ga,
+                                         float be, float zv, float dav, float& gout, float& xhat) {
   xhat = (zv - mu) * rs;
   float pre = xhat * ga + be;
   float gv = dav;
-  if (q.thr16) {
-    const bool keep = drop_keep(seed, eidx, q.thr16);
+  if constexpr (DROP) {
     pre = keep ? pre : 0.f;
     gv = keep ? gv * q.drop_scale : 0.f;
   }
   gout = pre > 0.f ? gv : gv * q.slope;
 }
 
-template <typename T>
+template <typename T, bool DROP>
 __global__ __launch_bounds__(256) void normact_bwd_reduce_kernel(const NormActArgs q) {
   constexpr int EPV = Elem<T>::kPer16B;
   const int g = blockIdx.y, b = blockIdx.x;
@@ -343,18 +357,19 @@ __global__ __launch_bounds__(256) void normact_bwd_reduce_kernel(const NormActAr
   float* out = q.part + ((long long)g * q.blocks_per_group + b) * 2 * q.c;
   BwdConst<EPV> k;
   load_bwd_const<EPV>(q, g, (int)(threadIdx.x % (q.c / EPV)) * EPV, k);
-  const unsigned long long seed = q.thr16 ? eff_seed(q.seed, q.seed_ptr) : 0ull;
+  const unsigned long long seed = DROP ? eff_seed(q.seed, q.seed_ptr) : 0ull;
   block_channel_sums<T>(q.c, r0, r1,
       [&](long long row, int ch0, float* s0, float* s1) {
         Vec16<T> zv, dv;
         zv.load(zb + row * q.ldz + ch0);
         if (q.s2d_da.d) dv.load(reinterpret_cast<const T*>(q.da) + s2d_offset(q.s2d_da, (long long)g * q.rows_per_group + row, q.ldda) + ch0);
         else dv.load(db + row * q.ldda + ch0);
-        const unsigned long long e0 = ((unsigned long long)g * q.rows_per_group + row) * q.c + ch0;
+        unsigned keep = 0;
+        if constexpr (DROP) keep = drop_keep_mask<EPV>(seed, ((unsigned long long)g * q.rows_per_group + row) * q.c + ch0, q.thr16);
 #pragma unroll
         for (int j = 0; j < EPV; ++j) {
           float gv, xh;
-          bwd_elem(q, seed, k.mu[j], k.rs[j], k.ga[j], k.be[j], zv.f[j], dv.f[j], e0 + j, gv, xh);
+          bwd_elem<DROP>(q, (keep >> j) & 1u, k.mu[j], k.rs[j], k.ga[j], k.be[j], zv.f[j], dv.f[j], gv, xh);
           s0[j] += gv;
           s1[j] += gv * xh;
         }
@@ -385,7 +400,7 @@ __global__ __launch_bounds__(1024) void normact_bwd_finalize_kernel(const float*
   }
 }
 
-template <typename T>
+template <typename T, bool DROP>
 __global__ __launch_bounds__(256) void normact_bwd_apply_kernel(const NormActArgs q) {
   constexpr int EPV = Elem<T>::kPer16B;
   const int g = blockIdx.y;
@@ -396,7 +411,7 @@ __global__ __launch_bounds__(256) void normact_bwd_apply_kernel(const NormActArg
   const float inv = 1.f / (float)q.rows_per_group;
   BwdConst<EPV> k;
   load_bwd_const<EPV>(q, g, ch0, k);
-  const unsigned long long seed = q.thr16 ? eff_seed(q.seed, q.seed_ptr) : 0ull;
+  const unsigned long long seed = DROP ? eff_seed(q.seed, q.seed_ptr) : 0ull;
   float kk[EPV], m0[EPV], m1[EPV];
 #pragma unroll
   for (int j = 0; j < EPV; ++j) {
@@ -415,11 +430,12 @@ __global__ __launch_bounds__(256) void normact_bwd_apply_kernel(const NormActArg
     zv.load(zb + row * q.ldz + ch0);
     if (q.s2d_da.d) dv.load(reinterpret_cast<const T*>(q.da) + s2d_offset(q.s2d_da, (long long)g * q.rows_per_group + row, q.ldda) + ch0);
     else dv.load(db + row * q.ldda + ch0);
-    const unsigned long long e0 = ((unsigned long long)g * q.rows_per_group + row) * q.c + ch0;
+    unsigned keep = 0;
+    if constexpr (DROP) keep = drop_keep_mask<EPV>(seed, ((unsigned long long)g * q.rows_per_group + row) * q.c + ch0, q.thr16);
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
       float gv, xh;
-      bwd_elem(q, seed, k.mu[j], k.rs[j], k.ga[j], k.be[j], zv.f[j], dv.f[j], e0 + j, gv, xh);
+      bwd_elem<DROP>(q, (keep >> j) & 1u, k.mu[j], k.rs[j], k.ga[j], k.be[j], zv.f[j], dv.f[j], gv, xh);
       zv.f[j] = kk[j] * (gv - m0[j] - xh * m1[j]);
     }
     zv.store(ob + row * q.lddz + ch0);
@@ -822,8 +838,13 @@ int mi355_normact_fwd(const mi355_normact_desc* d, void* stream) {
   if (rc) return rc;
   MI355_REQUIRE(d->a && d->lda >= d->c, "normact_fwd: bad output");
   dim3 grid(stream_blocks(d->rows_per_group, d->c, d->dtype), d->groups);
-  if (d->dtype == MI355_DT_F32) hipLaunchKernelGGL(normact_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, q);
-  else hipLaunchKernelGGL(normact_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, q);
+  if (d->dtype == MI355_DT_F32) {
+    if (q.thr16) normact_fwd_kernel<float, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+    else normact_fwd_kernel<float, false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+  } else {
+    if (q.thr16) normact_fwd_kernel<bf16_t, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+    else normact_fwd_kernel<bf16_t, false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+  }
   return mi355_check_launch("normact_fwd");
 }
 
@@ -833,8 +854,13 @@ int mi355_normact_bwd_reduce(const mi355_normact_desc* d, void* stream) {
   if (rc) return rc;
   MI355_REQUIRE(d->da && d->part && d->blocks_per_group > 0 && d->ldda >= d->c, "normact_bwd_reduce: bad argument");
   dim3 grid(d->blocks_per_group, d->groups);
-  if (d->dtype == MI355_DT_F32) hipLaunchKernelGGL(normact_bwd_reduce_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, q);
-  else hipLaunchKernelGGL(normact_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, q);
+  if (d->dtype == MI355_DT_F32) {
+    if (q.thr16) normact_bwd_reduce_kernel<float, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+    else normact_bwd_reduce_kernel<float, false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+  } else {
+    if (q.thr16) normact_bwd_reduce_kernel<bf16_t, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+    else normact_bwd_reduce_kernel<bf16_t, false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+  }
   return mi355_check_launch("normact_bwd_reduce");
 }
 
@@ -853,8 +879,13 @@ int mi355_normact_bwd_apply(const mi355_normact_desc* d, void* stream) {
   MI355_REQUIRE(d->da && d->dz && d->ldda >= d->c && d->lddz >= d->c, "normact_bwd_apply: bad argument");
   MI355_REQUIRE(!(d->mean && d->batch_stats) || d->sums, "normact_bwd_apply: sums required");
   dim3 grid(stream_blocks(d->rows_per_group, d->c, d->dtype), d->groups);
-  if (d->dtype == MI355_DT_F32) hipLaunchKernelGGL(normact_bwd_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, q);
-  else hipLaunchKernelGGL(normact_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, q);
+  if (d->dtype == MI355_DT_F32) {
+    if (q.thr16) normact_bwd_apply_kernel<float, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+    else normact_bwd_apply_kernel<float, false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+  } else {
+    if (q.thr16) normact_bwd_apply_kernel<bf16_t, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+    else normact_bwd_apply_kernel<bf16_t, false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+  }
   return mi355_check_launch("normact_bwd_apply");
 }
 
