@@ -38,6 +38,11 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 # dominant kernel family = full-resolution 3x3x3 implicit GEMM with 32 output channels
 # plan id = 10000*ks + 1000*halo + 100*tile_shape + 10*voxel_subtiles_per_wave + cout_subtiles_per_wave
 DOMINANT_PLAN = {"bf16": (31941, "conv_ru_kernel<1>"), "f32": (31021, "conv_halo_kernel<float,3,2,4,32,1>")}
+# HBM-side bytes per launch of the dominant kernel in THIS workload (1x24x128^3 GAN step), from rocprofv3 PMC passes
+# of the same step (`tools/pmc_step.sh`, profiles/r01_pmc_step_traffic.txt): 2 x FETCH_SIZE (gfx950 counts the 128-B
+# requests of 16-B/lane streams at 64 B) + WRITE_SIZE, averaged over the kernel's launches.  bench.py cannot collect
+# counters itself; other sizes / dtypes report null.
+PROFILED_TRAFFIC = {("bf16", 128, "gan_step"): 2 * 268627.3e3 + 153600.0e3}
 
 
 def parse():
@@ -241,7 +246,8 @@ def main():
         if s:
             ach = s["flops"] / (s["total_ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
-                               "frac": ach / PEAK_TFLOPS[a.dtype], "traffic": None,
+                               "frac": ach / PEAK_TFLOPS[a.dtype],
+                               "traffic": PROFILED_TRAFFIC.get((a.dtype, a.size, a.workload)) if a.batch == 1 else None,
                                "kernel": DOMINANT_PLAN[a.dtype][1],
                                "launches": s["launches"], "avg_launch_ms": s["avg_ms"], "measured": probe_mode}
         if world == 1 and not a.no_cpu_baseline:
