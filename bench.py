@@ -9,10 +9,12 @@ One "step" = one full ``training_step`` (src/model.py:259-281: generator phase +
 phase, both AdamW updates) on one 1x24x128^3 volume per GPU, inputs resident in HBM.  Rank 0
 prints ONE JSON line (metric/unit from BASELINE.json) carrying
 
-* ``roofline``     -- the dominant kernel family (3x3x3 implicit-GEMM conv at full resolution,
-  ``conv_k3_halo_kernel<T,2,4,32,1>``): algorithmic FLOPs of all its launches in the timed region
-  / their summed duration, measured live with HIP events on the launch stream; peak = dense MFMA
-  peak of the dtype (MI355X_MICROARCH.md: bf16 ~2.5 PF, f32-matrix 157.3 TF).
+* ``roofline``     -- the dominant kernel family (3x3x3 implicit-GEMM conv at full resolution with 32
+  output channels: ``conv_ru_kernel<1>`` in bf16, ``conv_halo_kernel<float,3,2,4,32,1>`` in f32):
+  algorithmic FLOPs of all its launches / their summed duration, measured live with HIP events on
+  the launch stream; peak = dense MFMA peak of the dtype (MI355X_MICROARCH.md: bf16 ~2.5 PF,
+  f32-matrix 157.3 TF); ``traffic`` = HBM-side bytes per launch from rocprofv3 PMC passes of the same
+  step (profiles/r01_pmc_step_traffic.txt).
 * ``cpu_baseline`` -- the CPU oracle (oracle/unet_ref.py, kind "port") timed on the host cores on
   a bounded sample (one step at the same 128^3 size), rank 0 at N=1 only.  A reported baseline,
   not the target.
