@@ -32,7 +32,7 @@ template <typename T, int VT, int CT>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[VT][CT],
                                               const long long (&yoff)[VT], int co_base,
                                               int tile_index, float* red /* LDS, >= 4*CT*64 floats */,
-                                              int co_store_base = -1) {
+                                              int co_store_base = -1, char* tpatch = nullptr /* LDS, 4 x 2 KB */) {
   if (co_store_base < 0) co_store_base = co_base;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -40,6 +40,44 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[V
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) { s1[ct] = 0.f; s2[ct] = 0.f; }
 
+  bool stored = false;
+  if constexpr (sizeof(T) == 2) {
+    // 16-bit outputs whose stored channel count is a multiple of 8: transpose each 32x32 tile through a
+    // wave-private LDS patch and write 16 bytes per lane (as conv_epilogue_tile does) instead of 2-byte stores
+    // -- the transposed-conv forward writes 8x its input volume and was store-issue bound (192 us for 268 MB).
+    if ((a.cstore & 7) == 0 && tpatch != nullptr) {
+      stored = true;
+      char* wbuf = tpatch + wave * 2048;
+#pragma unroll
+      for (int vt = 0; vt < VT; ++vt) {
+        const int lo = (int)(yoff[vt] & 0xffffffffll), hi = (int)(yoff[vt] >> 32);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const int co = co_store_base + ct * 32 + r;
+          const float bv = (a.bias && co < a.nbias) ? a.bias[co] : 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = acc_row(i, h);
+            const float v = acc[vt][ct][i];
+            if (__shfl(hi, row, 64) >= 0) { s1[ct] += v; s2[ct] += v * v; }
+            *reinterpret_cast<uint16_t*>(wbuf + row * 64 + r * 2) = f32_to_bf16_bits(v + bv);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const int co0 = co_store_base + ct * 32 + (lane & 3) * 8;
+#pragma unroll
+          for (int pass = 0; pass < 2; ++pass) {
+            const int vrow = pass * 16 + (lane >> 2);
+            const int olo = __shfl(lo, vrow, 64), ohi = __shfl(hi, vrow, 64);
+            const long long off = ((long long)ohi << 32) | (unsigned int)olo;
+            const uint4 val = *reinterpret_cast<const uint4*>(wbuf + vrow * 64 + (lane & 3) * 16);
+            if (off >= 0 && co0 + 8 <= a.cstore) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(a.y) + off + co0) = val;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+      }
+    }
+  }
+  if (!stored)
 #pragma unroll
   for (int vt = 0; vt < VT; ++vt) {
     const int lo = (int)(yoff[vt] & 0xffffffffll), hi = (int)(yoff[vt] >> 32);

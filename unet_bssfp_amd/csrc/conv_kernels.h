@@ -270,6 +270,7 @@ template <typename T, int VT, int CT>
 __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvArgs a) {
   constexpr int ES = sizeof(T);
   __shared__ float red[4 * CT * 64];
+  __shared__ __attribute__((aligned(16))) char tpatch[ES == 2 ? 4 * 2048 : 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int co_base = blockIdx.y * (32 * CT);
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvArgs a) {
                            (vh[vt] * a.os + oh)) * a.wy + (vw[vt] * a.os + ow)) * a.ldy
                        : -1;
   }
-  conv_epilogue<T, VT, CT>(a, acc, yoff, co_base, blockIdx.x, red, co_store);
+  conv_epilogue<T, VT, CT>(a, acc, yoff, co_base, blockIdx.x, red, co_store, ES == 2 ? tpatch : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
