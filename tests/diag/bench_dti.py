@@ -3,7 +3,7 @@ against the HBM roofline, and the oracle (numpy eigh, one core) on a bounded sam
 import argparse, json, os, sys, time
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from unet_bssfp_amd import eval as E
 
 ap = argparse.ArgumentParser()

@@ -1,6 +1,6 @@
 """Diagnostic (not a test): element-wise gradient / update agreement GPU vs oracle for one GAN step."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import torch.nn.functional as F
 from oracle import unet_ref as R
