@@ -299,11 +299,14 @@ class ConvFn(Function):
         if part is None:
             part = torch.empty((0,), dtype=torch.float32, device=dev)
         ctx.mark_non_differentiable(part)
+        ctx.set_materialize_grads(False)      # no zero tensor (+ fill launch) for the statistics output in every backward
         return out, part
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dz, _dpart):
+        if dz is None:                        # the conv output did not reach the loss
+            return (None,) * 8
         x0, x1, weight = ctx.saved_tensors
         spec: ConvSpec = ctx.spec
         dz = ops.as_act(dz)
