@@ -385,3 +385,46 @@ def test_normact_writes_and_reads_s2d(hip, dtype):
     a_plain.backward(to_act(ga, dtype))
     a_s2d.backward(to_s2d(ga, dtype, c))
     assert torch.equal(zd1.grad.float().cpu(), zd2.grad.float().cpu())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batched_repack_matches_single_pack(hip, dtype):
+    """After an optimiser step the packed weights are rebuilt by mi355_weight_pack_multi (dense 3x3x3 packings
+    through the LDS-transposing kernel, the rest through the gather kernel): must equal the single-descriptor
+    pack bit for bit, for forward and data-gradient layouts, padded channel counts included."""
+    from unet_bssfp_amd import functional as Fn, nn as N
+    ops = _ops()
+    torch.manual_seed(0)
+    net = torch.nn.ModuleList([N.Conv3d(24, 32, 3, 1, 1), N.Conv3d(96, 32, 3, 1, 1), N.Conv3d(32, 6, 3, 1, 1),
+                               N.Conv3d(64, 128, 3, 1, 1), N.Conv3d(24, 24, 1, 1, 0), N.ConvTranspose3d(64, 32),
+                               N.Conv3d(30, 32, 4, 2, 1)]).to(DEV)
+    packed = []
+    for m in net:
+        s, w = m.spec, m.weight
+        cinp = ops.round_up(s.cin, 16)
+        if s.kind == "conv" and s.stride == 1:
+            packed += [s.w_fwd(w, dtype, cinp)[0], s.w_dgrad_s1(w, dtype, ops.round_up(s.cout, 16), cinp)[0]]
+        elif s.kind == "conv":
+            packed += [s.w_fwd_s2d(w, dtype, 32)[0], s.w_dgrad_s2d(w, dtype, 32, 32)[0]]
+        else:
+            packed += [s.w_deconv_fwd_all(w, dtype, cinp)[0], s.w_deconv_dgrad(w, dtype, ops.round_up(s.cout, 16))[0]]
+    with torch.no_grad():
+        for m in net:
+            m.weight.mul_(1.5).add_(0.25)                     # "optimiser step": versions bump, caches go stale
+    Fn.repack_weights(net)                                    # batched path, in place
+    batched = [p.clone() for p in packed]
+    for m in net:
+        m.spec.cache.clear()                                  # rebuild through the single-descriptor path
+    k = 0
+    for m in net:
+        s, w = m.spec, m.weight
+        cinp = ops.round_up(s.cin, 16)
+        if s.kind == "conv" and s.stride == 1:
+            fresh = [s.w_fwd(w, dtype, cinp)[0], s.w_dgrad_s1(w, dtype, ops.round_up(s.cout, 16), cinp)[0]]
+        elif s.kind == "conv":
+            fresh = [s.w_fwd_s2d(w, dtype, 32)[0], s.w_dgrad_s2d(w, dtype, 32, 32)[0]]
+        else:
+            fresh = [s.w_deconv_fwd_all(w, dtype, cinp)[0], s.w_deconv_dgrad(w, dtype, ops.round_up(s.cout, 16))[0]]
+        for f in fresh:
+            assert torch.equal(f, batched[k]), (type(m).__name__, k)
+            k += 1

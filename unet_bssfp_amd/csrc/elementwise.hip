@@ -715,6 +715,57 @@ int mi355_weight_pack(const mi355_wpack_desc* d, void* stream) {
   return mi355_check_launch("weight_pack");
 }
 
+}  // extern "C"
+
+namespace {
+// Dense 3x3x3 weights W[R][C][27] (forward: R = cout, C = cin; data gradient: roles swapped, taps flipped): the
+// kernels above gather 4-byte elements 27 floats (or C*27 floats) apart -- 16x read amplification on 34 M
+// parameters after every optimiser step.  Here a block loads a 16 (R) x 16 (C) x 27 patch as 16 contiguous runs of
+// 432 floats, keeps it in LDS and writes the packed [chunk][tap][co][16] order 512 contiguous bytes per tap.
+template <typename T>
+__global__ __launch_bounds__(256) void wpack_dense3_multi_kernel(const WpackMulti m) {
+  const WpackArgs& a = m.a[blockIdx.y];
+  constexpr int NT = 27, ROW = 16 * NT + 1;
+  __shared__ float tile[16 * ROW];
+  const int nchunk = a.cinp / 16, ncob = a.coutp / 16;
+  if ((int)blockIdx.x >= nchunk * ncob) return;
+  const int chunk = blockIdx.x / ncob, cob = blockIdx.x % ncob;
+  const bool co_is_row = a.s_co > a.s_ci;                       // forward packing
+  const int r0 = (co_is_row ? cob : chunk) * 16, c0 = (co_is_row ? chunk : cob) * 16;
+  const int nr = co_is_row ? a.cout : a.cin, nc = co_is_row ? a.cin : a.cout;      // extents of W's two channel axes
+  const long long rstride = co_is_row ? a.s_co : a.s_ci;
+  const int cvalid = min(16, nc - c0);                          // may be <= 0: the patch is padding only
+  for (int rl = 0; rl < 16; ++rl) {
+    const float* src = a.src + (long long)(r0 + rl) * rstride + (long long)c0 * NT;
+    const bool rok = r0 + rl < nr;
+    for (int j = threadIdx.x; j < 16 * NT; j += 256) tile[rl * ROW + j] = (rok && j < cvalid * NT) ? src[j] : 0.f;
+  }
+  __syncthreads();
+  const int col = threadIdx.x >> 4, e = threadIdx.x & 15;       // output channel within the block, channel within the chunk
+  const int rl = co_is_row ? col : e, cl = co_is_row ? e : col;
+  T* dst = reinterpret_cast<T*>(a.dst) + ((long long)chunk * NT * a.coutp + (long long)cob * 16) * 16 + threadIdx.x;
+#pragma unroll
+  for (int tap = 0; tap < NT; ++tap) {
+    const int td = tap / 9, th = (tap / 3) % 3, tw = tap % 3;
+    const int ts = (a.tb0 + a.ts0 * td) * 9 + (a.tb1 + a.ts1 * th) * 3 + (a.tb2 + a.ts2 * tw);
+    Elem<T>::store(dst + (long long)tap * a.coutp * 16, tile[rl * ROW + cl * NT + ts]);
+  }
+}
+
+static bool wpack_is_dense3(const mi355_wpack_desc* d) {
+  if (d->ks != 3 || d->s2d_mode != 0 || d->s_k[2] != 1 || d->s_k[1] != 3 || d->s_k[0] != 9) return false;
+  const long long lo = d->s_co < d->s_ci ? d->s_co : d->s_ci, hi = d->s_co < d->s_ci ? d->s_ci : d->s_co;
+  const long long inner = d->s_co > d->s_ci ? d->cin : d->cout;              // channels along W's second axis
+  for (int k = 0; k < 3; ++k) {
+    const int first = d->tbase[k], last = d->tbase[k] + 2 * d->tstep[k];
+    if (first < 0 || first > 2 || last < 0 || last > 2) return false;
+  }
+  return lo == 27 && hi == 27 * inner;
+}
+}  // namespace
+
+extern "C" {
+
 static int fill_wpack(const mi355_wpack_desc* d, WpackArgs* a) {
   MI355_REQUIRE(d && d->src && d->dst, "weight_pack: null pointer");
   MI355_REQUIRE(d->coutp % 32 == 0 && d->cinp % 16 == 0 && d->cout <= d->coutp && d->cin <= d->cinp && d->ks >= 1 && d->ks <= 4,
@@ -733,23 +784,43 @@ int mi355_weight_pack_multi(const mi355_wpack_desc* descs, int32_t n, void* stre
   MI355_REQUIRE(descs && n > 0, "weight_pack_multi: bad argument");
   const int dtype = descs[0].dtype;
   MI355_REQUIRE(dtype == MI355_DT_F32 || dtype == MI355_DT_BF16, "weight_pack_multi: bad dtype");
-  for (int base = 0; base < n; base += kWpackChunk) {
-    const int cnt = n - base < kWpackChunk ? n - base : kWpackChunk;
-    WpackMulti m;
-    long long mx = 0;
-    for (int i = 0; i < kWpackChunk; ++i) {
-      const mi355_wpack_desc* d = &descs[base + (i < cnt ? i : 0)];
-      MI355_REQUIRE(d->dtype == dtype, "weight_pack_multi: mixed dtypes");
-      int rc = fill_wpack(d, &m.a[i]);
-      if (rc) return rc;
-      const long long total = (long long)d->cinp * d->ks * d->ks * d->ks * d->coutp;
-      if (i < cnt && total > mx) mx = total;
+  // two passes over the list: dense 3x3x3 packings go through the LDS-transposing kernel, the rest through the gather
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool want_dense = pass == 0;
+    int i0 = 0;
+    while (i0 < n) {
+      WpackMulti m;
+      int cnt = 0;
+      long long mx = 0, patches = 0;
+      const mi355_wpack_desc* firstd = nullptr;
+      for (; i0 < n && cnt < kWpackChunk; ++i0) {
+        const mi355_wpack_desc* d = &descs[i0];
+        MI355_REQUIRE(d->dtype == dtype, "weight_pack_multi: mixed dtypes");
+        if (wpack_is_dense3(d) != want_dense) continue;
+        int rc = fill_wpack(d, &m.a[cnt]);
+        if (rc) return rc;
+        if (!firstd) firstd = d;
+        const long long total = (long long)d->cinp * d->ks * d->ks * d->ks * d->coutp;
+        const long long np = (long long)(d->cinp / 16) * (d->coutp / 16);
+        if (total > mx) mx = total;
+        if (np > patches) patches = np;
+        ++cnt;
+      }
+      if (cnt == 0) break;
+      for (int i = cnt; i < kWpackChunk; ++i) m.a[i] = m.a[0];       // unused slots: never indexed (grid.y = cnt)
+      if (want_dense) {
+        MI355_REQUIRE(patches < (1ll << 31), "weight_pack_multi: too many patches");
+        dim3 grid((unsigned)patches, cnt);
+        if (dtype == MI355_DT_F32) wpack_dense3_multi_kernel<float><<<grid, dim3(256), 0, (hipStream_t)stream>>>(m);
+        else wpack_dense3_multi_kernel<bf16_t><<<grid, dim3(256), 0, (hipStream_t)stream>>>(m);
+      } else {
+        long long nb = (mx + 256 * 8 - 1) / (256 * 8);
+        if (nb > 512) nb = 512;
+        dim3 grid((unsigned)nb, cnt);
+        if (dtype == MI355_DT_F32) hipLaunchKernelGGL(wpack_multi_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, m);
+        else hipLaunchKernelGGL(wpack_multi_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, m);
+      }
     }
-    long long nb = (mx + 256 * 8 - 1) / (256 * 8);
-    if (nb > 512) nb = 512;
-    dim3 grid((unsigned)nb, cnt);
-    if (dtype == MI355_DT_F32) hipLaunchKernelGGL(wpack_multi_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, m);
-    else hipLaunchKernelGGL(wpack_multi_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, m);
   }
   return mi355_check_launch("weight_pack_multi");
 }
