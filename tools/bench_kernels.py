@@ -26,7 +26,7 @@ def timeit(fn, reps):
 
 
 def bench_conv(dtype, reps, only=None):
-    cases = [("32->32 @128^3", 32, 0, 32, 128), ("24(32)->32 @128^3", 32, 0, 32, 128), ("96->32 @128^3 (32|64)", 32, 64, 32, 128),
+    cases = [("32->32 @128^3", 32, 0, 32, 128), ("24(32)->32 @128^3", 32, 0, 32, 128), ("96->32 @128^3 (32|64)", 32, 64, 32, 128), ("32->96 @128^3", 32, 0, 96, 128),
              ("64->32 @64^3", 64, 0, 32, 64), ("32->64 @64^3", 32, 0, 64, 64), ("64->64 @64^3", 64, 0, 64, 64), ("128->64 @64^3 (64|64)", 64, 64, 64, 64), ("64->128 @32^3", 64, 0, 128, 32), ("128->128 @32^3", 128, 0, 128, 32), ("256->128 @32^3 (128|128)", 128, 128, 128, 32),
              ("128->64 @32^3", 128, 0, 64, 32), ("128->256 @32^3", 128, 0, 256, 32),
              ("128->256 @16^3", 128, 0, 256, 16), ("512->256 @16^3 (256|256)", 256, 256, 256, 16), ("256->128 @16^3", 256, 0, 128, 16),
