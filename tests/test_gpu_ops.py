@@ -75,6 +75,11 @@ CONV_CASES = [
     ("k3_cin24", 1, (24,), 32, (4, 4, 32), 3, 1, 1),
     ("k3_splitk", 2, (256,), 64, (4, 8, 8), 3, 1, 1),            # few positions, long contraction: split-K path
     ("k3_splitk_concat", 1, (128, 128), 96, (8, 8, 16), 3, 1, 1),
+    # wide layers that take the row-reuse / LDS-DMA kernel in bf16 (>= 1024 tiles of 4x4x32, or >= 512 with 64 channels)
+    ("k3_ru_ct1", 1, (32,), 32, (64, 64, 128), 3, 1, 1),
+    ("k3_ru_ragged_concat", 1, (32, 64), 32, (62, 66, 130), 3, 1, 1),
+    ("k3_ru_ct2_n2", 2, (16,), 64, (32, 64, 64), 3, 1, 1),
+    ("k3_ru_cout96", 1, (32,), 96, (64, 64, 128), 3, 1, 1),
     ("k4s2", 1, (30,), 32, (8, 8, 16), 4, 2, 1),
     ("k4s2_ct2", 2, (32,), 64, (8, 8, 8), 4, 2, 1),
     ("k1_head", 2, (24,), 24, (4, 4, 8), 1, 1, 0),
@@ -108,7 +113,14 @@ def test_conv_fwd_bwd(hip, case, dtype):
 
     layer = layer.to(DEV)
     acts = [to_act(x, dtype).requires_grad_(True) for x in xs]
-    z, part = Fn.ConvFn.apply(acts[0], acts[1] if len(acts) > 1 else None, layer.weight, layer.bias, layer.spec, True)
+    plans = []
+    _ops().CONV_PROBE = lambda pid, d, real: plans.append(pid)
+    try:
+        z, part = Fn.ConvFn.apply(acts[0], acts[1] if len(acts) > 1 else None, layer.weight, layer.bias, layer.spec, True)
+    finally:
+        _ops().CONV_PROBE = None
+    if name.startswith("k3_ru") and dtype == torch.bfloat16:
+        assert plans and plans[0] in (31941, 31942), plans      # conv_ru_kernel<1> / <2>
     tol = TOL[dtype]
     torch.testing.assert_close(from_act(z, cout), z_ref.detach(), **tol)
     cp = z.shape[4]
