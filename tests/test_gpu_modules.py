@@ -330,6 +330,28 @@ def test_full_size_128_forward_parity_with_oracle(hip):
     assert err <= 1e-4, err
 
 
+def test_thesis_volume_96x128x128_forward_parity(hip):
+    """The one I/O shape the reference documents for the whole generator (ONNX export rendered in
+    doc/thesis/img/model.onnx.png: 1x24x96x128x128 -> 1x6x96x128x128, the CropOrPad size of
+    src/data_module.py:124-127): non-cubic, every level ragged differently.  f32 parity with the oracle, bf16 runs."""
+    import unet_bssfp_amd as M
+    torch.manual_seed(0)
+    g = M.Generator("bssfp", dropout=0.0)
+    ref = R.RefGenerator("bssfp", dropout=0.0).train()
+    ref.load_state_dict(g.state_dict())
+    gen = torch.Generator().manual_seed(11)
+    x = torch.rand(1, 24, 96, 128, 128, generator=gen)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        y_ref = ref(x)
+        g = g.to(DEV).train()
+        y = g(x.to(DEV)).cpu()
+        assert y.shape == (1, 6, 96, 128, 128)
+        assert (y - y_ref).abs().mean().item() <= 1e-4
+        yb = M.set_compute_dtype(g, torch.bfloat16)(x.to(DEV)).cpu()
+    assert torch.isfinite(yb).all() and (yb - y_ref).abs().mean().item() <= 0.05 * max(y_ref.abs().mean().item(), 0.1)
+
+
 def test_config5_size_160_forward_parity_and_step(hip):
     """BASELINE.json configs[4] size (1x24x160^3: bottleneck 10^3, ragged 40/20/10-wide levels): f32 forward
     parity with the CPU oracle (per-voxel L1 <= 1e-4), then one full bf16 GAN step (finite losses, deterministic
