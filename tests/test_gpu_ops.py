@@ -144,7 +144,8 @@ def test_conv_fwd_bwd(hip, case, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("cin,cout,sp", [(64, 64, (2, 4, 8)), (128, 64, (4, 4, 4))])
+@pytest.mark.parametrize("cin,cout,sp", [(64, 64, (2, 4, 8)), (128, 64, (4, 4, 4)),
+                                         (64, 64, (64, 64, 33)), (128, 64, (32, 64, 65))])   # >= 131072 voxels: deconv_fwd_kernel in bf16
 def test_deconv_fwd_bwd(hip, dtype, cin, cout, sp):
     from unet_bssfp_amd.nn import ConvTranspose3d
     g = torch.Generator().manual_seed(5)
@@ -167,8 +168,11 @@ def test_deconv_fwd_bwd(hip, dtype, cin, cout, sp):
     z.backward(to_act(gz, dtype))
     btol = tol if dtype == torch.float32 else dict(rtol=5e-2, atol=1e-1)
     torch.testing.assert_close(from_act(a.grad, cin), x_cpu.grad, **btol)
-    torch.testing.assert_close(layer.weight.grad.cpu(), w_cpu.grad, rtol=tol["rtol"] * 5, atol=tol["atol"] * 50)
-    torch.testing.assert_close(layer.bias.grad.cpu(), b_cpu.grad, rtol=tol["rtol"] * 5, atol=tol["atol"] * 50)
+    # sums over all output positions of zero-mean values: the rounding noise of the (differently ordered) f32
+    # accumulations grows with sqrt(positions)
+    grow = max(1.0, (z_ref.numel() / cout) ** 0.5 / 30.0)
+    torch.testing.assert_close(layer.weight.grad.cpu(), w_cpu.grad, rtol=tol["rtol"] * 5, atol=tol["atol"] * 50 * grow)
+    torch.testing.assert_close(layer.bias.grad.cpu(), b_cpu.grad, rtol=tol["rtol"] * 5, atol=tol["atol"] * 50 * grow)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -47,6 +47,29 @@ def bench_conv(dtype, reps, only=None):
         print(f"conv fwd  {name:28s} {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TFLOP/s")
 
 
+def bench_deconv(dtype, reps, only=None):
+    """transposed conv k2 s2 (forward = one 1x1x1 GEMM with 8*Cout columns, data gradient = k2 s2 gather)"""
+    from unet_bssfp_amd.nn import ConvTranspose3d
+    for name, cin, cout, s in [("64->64 @64^3->128^3", 64, 64, 64), ("128->64 @32^3->64^3", 128, 64, 32), ("512->256 @8^3->16^3", 512, 256, 8)]:
+        if only and only not in name:
+            continue
+        layer = ConvTranspose3d(cin, cout).to(DEV)
+        from unet_bssfp_amd import nn as N
+        N.set_compute_dtype(layer, dtype)
+        x = torch.randn(1, s, s, s, cin, device=DEV).to(dtype).requires_grad_(True)
+        with torch.no_grad():
+            ms = timeit(lambda: layer.forward_act(x), reps)
+        es = 2 if dtype == torch.bfloat16 else 4
+        ob = 8 * s ** 3 * cout * es
+        print(f"deconv fwd {name:26s} {ms*1e3:9.1f} us  {ob/ms/1e6:8.1f} GB/s of output")
+        y = layer.forward_act(x)
+        g = torch.randn_like(y)
+        layer.weight.requires_grad_(False); layer.bias.requires_grad_(False)      # data gradient only
+        y = layer.forward_act(x)
+        ms = timeit(lambda: torch.autograd.grad(y, x, g, retain_graph=True), reps)
+        print(f"deconv dgrad {name:24s} {ms*1e3:9.1f} us  {ob/ms/1e6:8.1f} GB/s of dy")
+
+
 def bench_wgrad(dtype, reps, only=None):
     cases = [("32->32 @128^3", 32, 32, 128), ("96->32 @128^3", 96, 32, 128), ("64->64 @64^3", 64, 64, 64),
              ("128->128 @32^3", 128, 128, 32), ("256->256 @16^3", 256, 256, 16), ("512->512 @8^3", 512, 512, 8)]
@@ -95,6 +118,8 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     if a.what in ("conv", "all"):
         bench_conv(dt, a.reps, a.only)
+    if a.what in ("deconv", "all"):
+        bench_deconv(dt, a.reps, a.only)
     if a.what in ("wgrad", "all"):
         bench_wgrad(dt, a.reps, a.only)
     if a.what in ("norm", "all"):

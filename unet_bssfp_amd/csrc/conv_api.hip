@@ -206,6 +206,11 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
         }
       } else { HALO_KS(3) }
     } else { HALO_KS(2) }
+  } else if (sizeof(T) == 2 && d->cls_cout && p.vt == 2 && a.nchunks <= 8 && d->c1 == 0 && (d->cstore & 7) == 0) {
+    // transposed-conv forward, Cin <= 128: one workgroup per 256 voxels loops over all column blocks
+    const dim3 g1((unsigned)p.tiles);
+    if (a.nchunks <= 4) deconv_fwd_kernel<4><<<g1, block, 0, st>>>(a);
+    else deconv_fwd_kernel<8><<<g1, block, 0, st>>>(a);
   } else {
     if (p.vt == 2) {
       if (p.ct == 2) conv_gather_kernel<T, 2, 2><<<grid, block, 0, st>>>(a);

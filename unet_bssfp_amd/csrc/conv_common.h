@@ -70,7 +70,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[V
             const int olo = __shfl(lo, vrow, 64), ohi = __shfl(hi, vrow, 64);
             const long long off = ((long long)ohi << 32) | (unsigned int)olo;
             const uint4 val = *reinterpret_cast<const uint4*>(wbuf + vrow * 64 + (lane & 3) * 16);
-            if (off >= 0 && co0 + 8 <= a.cstore) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(a.y) + off + co0) = val;
+            if (off >= 0 && co0 + 8 <= a.cstore && !(a.ablate & 2)) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(a.y) + off + co0) = val;
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvArgs a) {
 #pragma unroll
       for (int vt = 0; vt < VT; ++vt) {
         Frag<T> af;
-        if (vox[vt] >= 0) af.load(src + (vox[vt] * ld + cbase) * ES + h * 16);
+        if (vox[vt] >= 0 && !(a.ablate & 1)) af.load(src + (vox[vt] * ld + cbase) * ES + h * 16);
         else af.zero();
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) mma16(af, b[ct], acc[vt][ct]);
@@ -503,4 +503,77 @@ __global__ __launch_bounds__(256, CT == 1 ? 4 : 2) void conv_ru_kernel(const Con
     to.wleft[vt] = a.wo - gw;
   }
   conv_epilogue_tile<T, VT, CT, TW, NW>(a, acc, to, co_base, tile, reinterpret_cast<float*>(smem));
+}
+
+// ------------------------------------------------------------------------------------------
+// deconv_fwd_kernel: ConvTranspose3d(k=2, s=2) forward in bf16 as ONE GEMM with 8*Cout columns (column block =
+// output parity class), Cin <= 128.  The gather kernel ran one workgroup per (256 voxels, 64 columns): 8192
+// workgroups of 16 MFMAs per wave whose index arithmetic, dependent fragment loads and epilogue set-up cost more
+// than the 268 MB they write (95 us with neither A loads nor stores, 153 us in full for 64->64 at 64^3).  Here a
+// workgroup owns 256 input voxels for ALL column blocks: the A fragments of its voxels (<= 8 chunks) are loaded
+// once and stay in registers, the loop over the 8*Cout/64 column blocks fetches weights, runs 8 * nchunks MFMAs
+// and writes one parity class of 64 channels (LDS-transposed 16-byte stores).
+// ------------------------------------------------------------------------------------------
+template <int MAXC>
+__global__ __launch_bounds__(256) void deconv_fwd_kernel(const ConvArgs a) {
+  using T = bf16_t;
+  constexpr int VT = 2, CT = 2;
+  __shared__ float red[4 * CT * 64];
+  __shared__ __attribute__((aligned(16))) char tpatch[4 * 2048];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+
+  int vn[VT], vd[VT], vh[VT], vw[VT];
+  bool vok[VT];
+  Frag<T> af[VT][MAXC];
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt) {
+    long long m = (long long)blockIdx.x * (128 * VT) + (wave * VT + vt) * 32 + r;
+    vok[vt] = m < a.m_total;
+    const long long vox = vok[vt] ? m : 0;
+    if (!vok[vt]) m = 0;
+    vw[vt] = (int)(m % a.wo); m /= a.wo;
+    vh[vt] = (int)(m % a.ho); m /= a.ho;
+    vd[vt] = (int)(m % a.do_);
+    vn[vt] = (int)(m / a.do_);
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      if (c < a.nchunks && vok[vt]) af[vt][c].load(a.x0 + (vox * a.ld0 + c * 16) * 2 + h * 16);
+      else af[vt][c].zero();
+    }
+  }
+  const long long wtap = (long long)a.coutp * 32;       // bytes per chunk of the packed [chunk][1 tap][coutp][16] weights
+  const int ncb = a.coutp / 64;
+  for (int cb = 0; cb < ncb; ++cb) {
+    const int co_base = cb * 64;
+    const char* wlane = a.wp + ((long long)co_base + r) * 32 + h * 16;
+    f32x16 acc[VT][CT];
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[vt][ct][i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      if (c < a.nchunks) {
+        Frag<T> b[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) b[ct].load(wlane + c * wtap + ct * 1024);
+#pragma unroll
+        for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) mma16(af[vt][c], b[ct], acc[vt][ct]);
+      }
+    }
+    const int cls = co_base / a.cls_cout, co_store = co_base - cls * a.cls_cout;
+    const int od = cls >> 2, oh = (cls >> 1) & 1, ow = cls & 1;
+    long long yoff[VT];
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt)
+      yoff[vt] = vok[vt] ? ((((long long)vn[vt] * a.dy + (vd[vt] * 2 + od)) * a.hy + (vh[vt] * 2 + oh)) * a.wy + (vw[vt] * 2 + ow)) * a.ldy : -1;
+    ConvArgs q = a;
+    q.stats = nullptr;
+    conv_epilogue<T, VT, CT>(q, acc, yoff, co_base, blockIdx.x, red, co_store, tpatch);
+  }
 }
