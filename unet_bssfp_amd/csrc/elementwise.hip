@@ -166,11 +166,11 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict_
 }
 
 // Sum of per-block/per-tile partials part[k][2][c] over k for 8 channels per workgroup:
-// 1024 threads = 8 channels x 128 partial lanes, f64 accumulate, fixed-order LDS tree (deterministic).
+// 1024 threads = 8 channels x 128 partial lanes, f64 accumulate, fixed-order shuffle + LDS combine (deterministic).
 // The totals of channel ch0 + (tid & 7) are returned to the threads with tid < 8.
 __device__ __forceinline__ void block_sum_parts(const float* __restrict__ part, int nparts, int c, int ch0,
                                                 double& t0, double& t1) {
-  __shared__ double red[128][8][2];
+  __shared__ double red[16][8][2];
   const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
   const int ch = ch0 + cl;
   double s0 = 0.0, s1 = 0.0;
@@ -189,18 +189,21 @@ __device__ __forceinline__ void block_sum_parts(const float* __restrict__ part, 
       s1 += (double)part[(long long)k * 2 * c + c + ch];
     }
   }
-  red[pl][cl][0] = s0;
-  red[pl][cl][1] = s1;
-  __syncthreads();
-  for (int o = 64; o > 0; o >>= 1) {
-    if (pl < o) {
-      red[pl][cl][0] += red[pl + o][cl][0];
-      red[pl][cl][1] += red[pl + o][cl][1];
-    }
-    __syncthreads();
+  // the 8 partial lanes of a wave (lane bits 3..5) by shuffles, then the 16 waves through LDS in a fixed order:
+  // two barriers instead of a 7-level LDS tree (these kernels are pure latency: ~90 launches per step)
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) {
+    s0 += __shfl_xor(s0, o, 64);
+    s1 += __shfl_xor(s1, o, 64);
   }
-  t0 = red[0][cl][0];
-  t1 = red[0][cl][1];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) < 8) { red[wave][cl][0] = s0; red[wave][cl][1] = s1; }
+  __syncthreads();
+  double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) { a0 += red[w][cl][0]; a1 += red[w][cl][1]; }
+  t0 = a0;
+  t1 = a1;
   __syncthreads();      // red is reused by the caller's next call
 }
 
