@@ -1,6 +1,7 @@
 // HBM-bound kernels of the path: layout pack/unpack, weight packing, channel statistics,
 // fused norm + dropout + LeakyReLU (forward / backward), max-pool, L1 loss, multi-tensor AdamW.
 // NDHWC rows are read and written as 16-byte vectors per lane (coalesced along channels).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -902,7 +903,9 @@ static unsigned stream_blocks(long long rows, int c, int dtype) {
   const int rpp = 256 / (c / epv);
   long long b = (rows + (long long)rpp * 8 - 1) / ((long long)rpp * 8);
   if (b < 1) b = 1;
-  if (b > 4096) b = 4096;
+  // 4 workgroups per CU, each streaming a long row range: measured against 256 ... 16384 in the full step
+  // (interleaved A/B): 1024 and 768 best, 4096 +0.12 ms, 256 +0.75 ms
+  if (b > 1024) b = 1024;
   return (unsigned)b;
 }
 
