@@ -38,6 +38,9 @@ def test_gpu_metrics_match_oracle(shape):
         assert got.shape == want.shape == (shape[0], 1), name
         assert torch.allclose(got, want, atol=tol, rtol=1e-5), (name, got, want)
     assert torch.equal(M.SSIMMetric(3)(pd, yd), M.SSIMMetric(3)(pd, yd))           # deterministic
+    if min(shape[2:]) >= 16:                                                       # a non-default window: runtime-length loops
+        got, want = M.SSIMMetric(3, win_size=7, kernel_sigma=1.0)(pd, yd).cpu(), MR.ssim3d(p, y, win_size=7, kernel_sigma=1.0)
+        assert torch.allclose(got, want, atol=2e-5, rtol=1e-5)
 
 
 @pytest.mark.gpu

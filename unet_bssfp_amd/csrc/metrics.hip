@@ -54,7 +54,10 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restr
   }
 }
 
+// The window length is a template parameter (WIN = 11 for MONAI's default, 0 = runtime): with a compile-time trip
+// count the tap loops unroll and their loads go out together (the runtime loops had one load in flight per lane).
 // pass W: rows = items*C*D*H rows of W floats -> 5 fields of Wo = W - n + 1
+template <int WIN>
 __global__ __launch_bounds__(256) void ssim_pass_w_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                           float* __restrict__ out, long long rows, int w, int wo, Gauss G) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -62,7 +65,9 @@ __global__ __launch_bounds__(256) void ssim_pass_w_kernel(const float* __restric
   const long long row = i / wo; const int o = (int)(i - row * wo);
   const float* px = x + row * w + o; const float* py = y + row * w + o;
   float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
-  for (int k = 0; k < G.n; ++k) {
+  const int n = WIN ? WIN : G.n;
+#pragma unroll
+  for (int k = 0; k < n; ++k) {
     const float a = px[k], b = py[k], g = G.g[k];
     sx += g * a; sy += g * b; sxx += g * (a * a); syy += g * (b * b); sxy += g * (a * b);
   }
@@ -71,6 +76,7 @@ __global__ __launch_bounds__(256) void ssim_pass_w_kernel(const float* __restric
 }
 
 // pass H: planes = 5*items*C*D planes of [h][wo] -> [ho][wo]
+template <int WIN>
 __global__ __launch_bounds__(256) void ssim_pass_h_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                           long long planes, int h, int ho, int wo, Gauss G) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -80,11 +86,14 @@ __global__ __launch_bounds__(256) void ssim_pass_h_kernel(const float* __restric
   const int oh = (int)(r / wo), ow = (int)(r - (long long)oh * wo);
   const float* p = in + (pl * h + oh) * wo + ow;
   float s = 0.f;
-  for (int k = 0; k < G.n; ++k) s += G.g[k] * p[(long long)k * wo];
+  const int n = WIN ? WIN : G.n;
+#pragma unroll
+  for (int k = 0; k < n; ++k) s += G.g[k] * p[(long long)k * wo];
   out[i] = s;
 }
 
 // pass D + SSIM formula + per-block sum.  grid (blocks, items*C); in: [5][items*C][d][ho][wo]
+template <int WIN>
 __global__ __launch_bounds__(256) void ssim_pass_d_kernel(const float* __restrict__ in, double* __restrict__ part,
                                                           long long nvol, int d, int dd, int ho, int wo, float c1, float c2, Gauss G) {
   __shared__ double red[4];
@@ -95,10 +104,12 @@ __global__ __launch_bounds__(256) void ssim_pass_d_kernel(const float* __restric
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long long)gridDim.x * 256) {
     const float* p = base + i;                                 // (od, oh, ow) flattened == offset of the first tap
     float m[5];
+    const int n = WIN ? WIN : G.n;
 #pragma unroll
     for (int f = 0; f < 5; ++f) {
       float s = 0.f;
-      for (int k = 0; k < G.n; ++k) s += G.g[k] * p[f * fs + (long long)k * plane];
+#pragma unroll
+      for (int k = 0; k < n; ++k) s += G.g[k] * p[f * fs + (long long)k * plane];
       m[f] = s;
     }
     const float sx = m[2] - m[0] * m[0], sy = m[3] - m[1] * m[1], sxy = m[4] - m[0] * m[1];
@@ -148,11 +159,18 @@ extern "C" int mi355_ssim3d(const float* x, const float* y, int32_t items, int32
   double* part = (double*)(((uintptr_t)(f2 + 5 * nvol * d * ho * wo) + 255) & ~(uintptr_t)255);
   hipStream_t st = (hipStream_t)stream;
   const long long rows = nvol * d * h;
-  ssim_pass_w_kernel<<<(unsigned)((rows * wo + 255) / 256), 256, 0, st>>>(x, y, f1, rows, w, (int)wo, G);
   const long long planes = 5 * nvol * d;
-  ssim_pass_h_kernel<<<(unsigned)((planes * ho * wo + 255) / 256), 256, 0, st>>>(f1, f2, planes, h, (int)ho, (int)wo, G);
   const int nb = blocks_for(dd * ho * wo);
-  ssim_pass_d_kernel<<<dim3(nb, (unsigned)nvol), 256, 0, st>>>(f2, part, nvol, d, (int)dd, (int)ho, (int)wo, c1, c2, G);
+  const unsigned gw = (unsigned)((rows * wo + 255) / 256), gh = (unsigned)((planes * ho * wo + 255) / 256);
+  if (win == 11) {
+    ssim_pass_w_kernel<11><<<gw, 256, 0, st>>>(x, y, f1, rows, w, (int)wo, G);
+    ssim_pass_h_kernel<11><<<gh, 256, 0, st>>>(f1, f2, planes, h, (int)ho, (int)wo, G);
+    ssim_pass_d_kernel<11><<<dim3(nb, (unsigned)nvol), 256, 0, st>>>(f2, part, nvol, d, (int)dd, (int)ho, (int)wo, c1, c2, G);
+  } else {
+    ssim_pass_w_kernel<0><<<gw, 256, 0, st>>>(x, y, f1, rows, w, (int)wo, G);
+    ssim_pass_h_kernel<0><<<gh, 256, 0, st>>>(f1, f2, planes, h, (int)ho, (int)wo, G);
+    ssim_pass_d_kernel<0><<<dim3(nb, (unsigned)nvol), 256, 0, st>>>(f2, part, nvol, d, (int)dd, (int)ho, (int)wo, c1, c2, G);
+  }
   sum_partials_kernel<<<items, 256, 0, st>>>(part, c * nb, 1, out, 1.0 / ((double)c * dd * ho * wo));
   return mi355_check_launch("ssim3d");
 }
