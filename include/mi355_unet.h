@@ -320,6 +320,18 @@ int mi355_ssim3d(const float* x, const float* y, int32_t items, int32_t c, int32
                  int32_t win, const float* window, float c1, float c2, void* workspace,
                  int64_t workspace_bytes, double* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Intensity augmentations of the training transform (src/data_module.py:130-139), GPU side:
+ * tio.RandomBiasField (x * exp(polynomial field), `coefficients` = HOST array of
+ * (order+1)(order+2)(order+3)/6 values in TorchIO's x-y-z loop order, order <= 4), tio.RandomGamma
+ * (sign(x) |x|^gamma) and tio.RandomNoise (x + N(mean, std^2), counter-based noise from `seed`).
+ * f32, (C, D, H, W) contiguous; in-place allowed (out == x).  Random PARAMETERS are drawn by the caller.
+ * ---------------------------------------------------------------------------------------- */
+int mi355_aug_bias_field(const float* x, float* out, int32_t c, int32_t d, int32_t h, int32_t w,
+                         const float* coefficients, int32_t order, void* stream);
+int mi355_aug_gamma(const float* x, float* out, int64_t count, float gamma, void* stream);
+int mi355_aug_noise(const float* x, float* out, int64_t count, float mean, float std, uint64_t seed, void* stream);
+
 /* layout probe used by the tests: writes lane -> (row, col) maps of the MFMA accumulators */
 int mi355_mfma_selftest(float* out_f32_1024, float* out_bf16_1024, void* stream);
 

@@ -95,6 +95,9 @@ _SIGNATURES = {
     "mi355_err_sums": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "mi355_ssim3d_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "mi355_ssim3d": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _f32, _f32, _vp, _i64, _vp, _vp]),
+    "mi355_aug_bias_field": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "mi355_aug_gamma": (C.c_int, [_vp, _vp, _i64, _f32, _vp]),
+    "mi355_aug_noise": (C.c_int, [_vp, _vp, _i64, _f32, _f32, C.c_uint64, _vp]),
     "mi355_mfma_selftest": (C.c_int, [_vp, _vp, _vp]),
 }
 
