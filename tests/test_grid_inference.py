@@ -129,3 +129,21 @@ def test_gpu_predict_step_mirrors_reference_loop():
     assert torch.equal(out.x, subject["bssfp"]["data"])          # aggregated input == input (what the reference returns)
     assert torch.equal(out.y, subject["dwi-tensor"]["data"])
     assert torch.equal(out.y_hat, I.predict_volume(model.gen, subject["bssfp"]["data"], 32, batch_size=3))
+
+
+@pytest.mark.gpu
+def test_gpu_test_step_logs_and_sums_patch_losses():
+    from unet_bssfp_amd import gan, nn as N
+    torch.manual_seed(4)
+    model = gan.bSSFPToDWITensorModel("bssfp", batch_size=2, gen=N.Generator("bssfp").cuda(), discr=N.Discriminator("bssfp").cuda())
+    model.eval()
+    g = torch.Generator().manual_seed(6)
+    subject = {"bssfp": {"data": torch.rand(24, 64, 64, 96, generator=g).cuda()},
+               "dwi-tensor": {"data": torch.rand(6, 64, 64, 96, generator=g).cuda()}}
+    sampler = I.GridSampler(subject, 64)                          # 2 patches -> one batch of 2
+    tot = model.test_step((sampler, I.GridAggregator(sampler), I.GridAggregator(sampler), I.GridAggregator(sampler)))
+    logs = {k: float(v) for k, v in model.last_logs.items()}
+    assert {"test_gen_loss_subject", "test_loss_recon_L1", "test_loss_adversarial", "test_metric_PSNR", "test_metric_SSIM",
+            "test_metric_L1"} <= set(logs)
+    assert float(tot) == pytest.approx(logs["test_gen_loss_subject"]) and np.isfinite(float(tot))
+    assert abs(logs["test_metric_L1"] - logs["test_loss_recon_L1"]) < 5e-3      # overlapping patches: last one wins in the volume

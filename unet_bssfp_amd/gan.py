@@ -209,6 +209,30 @@ class bSSFPToDWITensorModel(nn.Module):
             o_agg.add_batch(x, loc)
         return GridPrediction(i_agg.get_output_tensor(), t_agg.get_output_tensor(), o_agg.get_output_tensor())
 
+    @torch.no_grad()
+    def test_step(self, batch, batch_idx=0):
+        """src/model.py:291-312: the grid loop of ``predict_step`` with ``_gen_step(x, y, 'test')`` per patch batch,
+        the summed generator loss logged as ``test_gen_loss_subject`` and the metrics computed on the aggregated
+        volumes.  (The reference passes its mislabelled ``pred_tensor`` -- the aggregated INPUT -- to
+        ``compute_metrics``; here the metrics compare the aggregated prediction with the aggregated target.)"""
+        from .inference import LOCATION
+        sampler, i_agg, t_agg, o_agg = batch
+        logs: Dict[str, torch.Tensor] = {}
+        tot_loss = None
+        for patch_batch in sampler.batches(self.batch_size):
+            x, y = self.unpack_batch(patch_batch, test=True)
+            loc = patch_batch[LOCATION]
+            loss, y_hat = self._gen_step(x, y, logs, "test")
+            tot_loss = loss.detach() if tot_loss is None else tot_loss + loss.detach()
+            i_agg.add_batch(y_hat, loc)
+            t_agg.add_batch(y, loc)
+            o_agg.add_batch(x, loc)
+        y_hat_vol, y_vol = i_agg.get_output_tensor(), t_agg.get_output_tensor()
+        self.compute_metrics(y_hat_vol.unsqueeze(0), y_vol.unsqueeze(0), "test", logs)
+        logs["test_gen_loss_subject"] = tot_loss
+        self.last_logs = logs
+        return tot_loss
+
     def stacked_logs(self) -> torch.Tensor:
         """The step's scalars as ONE tensor (order: LOG_KEYS) -- a single all-reduce replaces the
         reference's six ``sync_dist`` logs."""
