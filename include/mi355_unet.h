@@ -241,6 +241,12 @@ int mi355_maxpool2_bwd(const void* x, int32_t ldx, const void* y, int32_t ldy,
                        const void* dy, int32_t lddy, void* dx, int32_t lddx,
                        int32_t n, int32_t c, int32_t d, int32_t h, int32_t w,
                        int32_t dtype, void* stream);
+/* same, plus `add` (a second gradient of the pooled tensor: the skip-connection use of a U-Net encoder
+ * level, src/model.py:22-28 via BasicUNet's skip concat) summed into dx in the same pass */
+int mi355_maxpool2_bwd_add(const void* x, int32_t ldx, const void* y, int32_t ldy, const void* dy, int32_t lddy,
+                           void* dx, int32_t lddx, const void* add, int32_t ldadd,
+                           int32_t n, int32_t c, int32_t d, int32_t h, int32_t w,
+                           int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Losses -- torch.nn.L1Loss (src/model.py:126,136): mean |a - b| over `count` f32 elements.

@@ -5,6 +5,7 @@ summation order: rtol 2e-4 / atol 2e-5 on O(1) data.  bf16 path (bf16 storage, f
 rtol 3e-2 / atol 3e-2.
 """
 import math
+import zlib
 
 import pytest
 import torch
@@ -99,7 +100,7 @@ def _conv_layer(cins, cout, ks, stride, pad, seed):
 def test_conv_fwd_bwd(hip, case, dtype):
     from unet_bssfp_amd import functional as Fn
     name, n, cins, cout, sp, ks, stride, pad = case
-    g = torch.Generator().manual_seed(hash(name) % 1000)
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)     # (str hash is salted per process)
     layer = _conv_layer(cins, cout, ks, stride, pad, 1)
     with torch.no_grad():
         layer.weight.copy_(q(layer.weight, dtype))       # weights representable in the compute dtype
@@ -139,8 +140,11 @@ def test_conv_fwd_bwd(hip, case, dtype):
         torch.testing.assert_close(from_act(a.grad, c), xcat.grad[:, off:off + c], **btol)
         off += c
     wscale = float(w_cpu.grad.abs().max())
-    torch.testing.assert_close(layer.weight.grad.cpu(), w_cpu.grad, rtol=tol["rtol"] * 5, atol=tol["atol"] * 5 * max(1.0, wscale))
-    torch.testing.assert_close(layer.bias.grad.cpu(), b_cpu.grad, rtol=tol["rtol"] * 5, atol=tol["atol"] * 50)
+    # sums over all output positions of zero-mean values: rounding noise of differently ordered f32 accumulations
+    # grows with sqrt(positions)
+    grow = max(1.0, (z_ref.numel() / cout) ** 0.5 / 30.0)
+    torch.testing.assert_close(layer.weight.grad.cpu(), w_cpu.grad, rtol=tol["rtol"] * 5, atol=tol["atol"] * 5 * max(1.0, wscale) * grow)
+    torch.testing.assert_close(layer.bias.grad.cpu(), b_cpu.grad, rtol=tol["rtol"] * 5, atol=tol["atol"] * 50 * grow)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -444,3 +448,32 @@ def test_batched_repack_matches_single_pack(hip, dtype):
         for f in fresh:
             assert torch.equal(f, batched[k]), (type(m).__name__, k)
             k += 1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_skip_pool_sums_both_gradients_in_the_pool_backward(hip, dtype):
+    """SkipPoolFn: one node for the two uses of an encoder level (skip connection + MaxPool3d(2)); its backward adds
+    the skip gradient -- here a channel slice of a wider buffer, as the concat conv's data gradient is -- inside the
+    max-pool backward kernel.  Reference: plain autograd on the CPU."""
+    from unet_bssfp_amd import functional as Fn
+    g = torch.Generator().manual_seed(9)
+    x = q(torch.rand(2, 32, 8, 12, 16, generator=g), dtype)
+    gs = q(torch.rand(2, 32, 8, 12, 16, generator=g) - 0.5, dtype)
+    gp = q(torch.rand(2, 32, 4, 6, 8, generator=g) - 0.5, dtype)
+    xr = x.clone().requires_grad_(True)
+    (xr * gs).sum().backward(retain_graph=True)
+    (F.max_pool3d(xr, 2) * gp).sum().backward()
+    a = to_act(x, dtype).requires_grad_(True)
+    skip, pooled = Fn.SkipPoolFn.apply(a)
+    assert torch.equal(skip, a) and torch.equal(from_act(pooled, 32), F.max_pool3d(x, 2))
+    wide = torch.zeros(2, 8, 12, 16, 48, dtype=dtype, device=DEV)
+    wide[..., :32] = to_act(gs, dtype)
+    torch.autograd.backward([skip, pooled], [wide[..., :32], to_act(gp, dtype)])
+    torch.testing.assert_close(from_act(a.grad, 32), xr.grad, **TOL[dtype])
+    # only one of the two uses reaches the loss
+    a2 = to_act(x, dtype).requires_grad_(True)
+    s2, p2 = Fn.SkipPoolFn.apply(a2)
+    p2.backward(to_act(gp, dtype))
+    x2 = x.clone().requires_grad_(True)
+    (F.max_pool3d(x2, 2) * gp).sum().backward()
+    torch.testing.assert_close(from_act(a2.grad, 32), x2.grad, **TOL[dtype])

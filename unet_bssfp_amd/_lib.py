@@ -82,6 +82,7 @@ _SIGNATURES = {
     "mi355_colsum_finalize": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "mi355_maxpool2_fwd": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mi355_maxpool2_bwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mi355_maxpool2_bwd_add": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mi355_l1_blocks": (_i32, [_i64]),
     "mi355_l1_fwd": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "mi355_l1_bwd": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),

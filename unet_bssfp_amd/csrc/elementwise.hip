@@ -484,7 +484,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ y,
                                                            int ldy, const T* __restrict__ dy, int lddy,
                                                            T* __restrict__ dx, int lddx, int c, int d, int h, int w,
-                                                           long long total) {
+                                                           long long total, const T* __restrict__ add, int ldadd) {
   constexpr int EPV = Elem<T>::kPer16B;
   const int lpr = c / EPV;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -515,6 +515,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
           const bool hit = !taken[j] && (v.f[j] == m.f[j] || v.f[j] != v.f[j]);
           outv.f[j] = hit ? g.f[j] : 0.f;
           taken[j] = taken[j] || hit;
+        }
+        if (add) {            // second gradient of the pooled tensor (its skip-connection use): summed here in f32
+          Vec16<T> s2;
+          s2.load(add + vox * ldadd + piece * EPV);
+#pragma unroll
+          for (int j = 0; j < EPV; ++j) outv.f[j] += s2.f[j];
         }
         outv.store(dx + vox * lddx + piece * EPV);
       }
@@ -984,8 +990,9 @@ int mi355_maxpool2_fwd(const void* x, int32_t ldx, void* y, int32_t ldy, int32_t
   return mi355_check_launch("maxpool_fwd");
 }
 
-int mi355_maxpool2_bwd(const void* x, int32_t ldx, const void* y, int32_t ldy, const void* dy, int32_t lddy, void* dx,
-                       int32_t lddx, int32_t n, int32_t c, int32_t d, int32_t h, int32_t w, int32_t dtype, void* stream) {
+static int maxpool_bwd_impl(const void* x, int32_t ldx, const void* y, int32_t ldy, const void* dy, int32_t lddy, void* dx,
+                            int32_t lddx, const void* add, int32_t ldadd, int32_t n, int32_t c, int32_t d, int32_t h,
+                            int32_t w, int32_t dtype, void* stream) {
   MI355_REQUIRE(x && y && dy && dx && n > 0, "maxpool_bwd: bad argument");
   MI355_REQUIRE(d % 2 == 0 && h % 2 == 0 && w % 2 == 0 && d > 0 && h > 0 && w > 0, "maxpool: extents must be even");
   int rc = check_rows(c, ldx, dtype, "maxpool_bwd");
@@ -993,14 +1000,27 @@ int mi355_maxpool2_bwd(const void* x, int32_t ldx, const void* y, int32_t ldy, c
   if ((rc = check_rows(c, ldy, dtype, "maxpool_bwd"))) return rc;
   if ((rc = check_rows(c, lddy, dtype, "maxpool_bwd"))) return rc;
   if ((rc = check_rows(c, lddx, dtype, "maxpool_bwd"))) return rc;
+  if (add && (rc = check_rows(c, ldadd, dtype, "maxpool_bwd"))) return rc;
   const int epv = dtype == MI355_DT_F32 ? 4 : 8;
   const long long total = (long long)n * (d / 2) * (h / 2) * (w / 2) * (c / epv);
   dim3 grid((unsigned)((total + 255) / 256));
   if (dtype == MI355_DT_F32)
-    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (const float*)y, ldy, (const float*)dy, lddy, (float*)dx, lddx, c, d, h, w, total);
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (const float*)y, ldy, (const float*)dy, lddy, (float*)dx, lddx, c, d, h, w, total, (const float*)add, ldadd);
   else
-    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)y, ldy, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, c, d, h, w, total);
+    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)y, ldy, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, c, d, h, w, total, (const bf16_t*)add, ldadd);
   return mi355_check_launch("maxpool_bwd");
+}
+
+int mi355_maxpool2_bwd(const void* x, int32_t ldx, const void* y, int32_t ldy, const void* dy, int32_t lddy, void* dx,
+                       int32_t lddx, int32_t n, int32_t c, int32_t d, int32_t h, int32_t w, int32_t dtype, void* stream) {
+  return maxpool_bwd_impl(x, ldx, y, ldy, dy, lddy, dx, lddx, nullptr, 0, n, c, d, h, w, dtype, stream);
+}
+
+int mi355_maxpool2_bwd_add(const void* x, int32_t ldx, const void* y, int32_t ldy, const void* dy, int32_t lddy, void* dx,
+                           int32_t lddx, const void* add, int32_t ldadd, int32_t n, int32_t c, int32_t d, int32_t h,
+                           int32_t w, int32_t dtype, void* stream) {
+  MI355_REQUIRE(add, "maxpool_bwd_add: null pointer");
+  return maxpool_bwd_impl(x, ldx, y, ldy, dy, lddy, dx, lddx, add, ldadd, n, c, d, h, w, dtype, stream);
 }
 
 int32_t mi355_l1_blocks(int64_t count) { return (int32_t)((count + kL1PerBlock - 1) / kL1PerBlock); }

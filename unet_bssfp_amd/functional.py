@@ -483,6 +483,31 @@ class MaxPoolFn(Function):
         return ops.maxpool2_bwd(x, y, ops.as_act(dy))
 
 
+class SkipPoolFn(Function):
+    """An encoder level's output is used twice: by the skip connection and by MaxPool3d(2) (MONAI BasicUNet).
+    Returning both uses from ONE autograd node lets the backward see both gradients at once and sum them inside
+    the max-pool backward kernel, instead of the engine launching a separate add over the full-resolution tensor."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = ops.as_act(x)
+        y = ops.maxpool2_fwd(x)
+        ctx.save_for_backward(x, y)
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_skip, d_pool):
+        if d_pool is None:
+            return d_skip
+        x, y = ctx.saved_tensors
+        add = None
+        if d_skip is not None:
+            add = d_skip if d_skip.stride(4) == 1 and d_skip.dtype == x.dtype else ops.as_act(d_skip)
+        return ops.maxpool2_bwd(x, y, ops.as_act(d_pool), add)
+
+
 class L1LossFn(Function):
     """torch.nn.L1Loss()(a, b) (mean reduction) on contiguous f32 tensors (src/model.py:126,136)."""
 

@@ -253,6 +253,11 @@ class Down(_Mi355Module):
     def forward_act(self, x):
         return self.convs.forward_act(Fn.MaxPoolFn.apply(x))
 
+    def forward_skip(self, x):
+        """-> (x for the skip connection, this level's output): both uses of x leave one autograd node"""
+        skip, pooled = Fn.SkipPoolFn.apply(x)
+        return skip, self.convs.forward_act(pooled)
+
 
 class _UpSample(nn.Module):
     def __init__(self, cin, cout):
@@ -312,14 +317,14 @@ class BasicUNet(_Mi355Module):
                 raise ValueError(f"spatial extents must be divisible by 16 and >= 32 (InstanceNorm needs > 1 "
                                  f"element at the bottom level), got {tuple(x.shape[1:4])}")
         x0 = self.conv_0.forward_act(x)
-        x1 = self.down_1.forward_act(x0)
-        x2 = self.down_2.forward_act(x1)
-        x3 = self.down_3.forward_act(x2)
-        x4 = self.down_4.forward_act(x3)
-        u4 = self.upcat_4.forward_act(x4, x3)
-        u3 = self.upcat_3.forward_act(u4, x2)
-        u2 = self.upcat_2.forward_act(u3, x1)
-        u1 = self.upcat_1.forward_act(u2, x0)
+        s0, x1 = self.down_1.forward_skip(x0)
+        s1, x2 = self.down_2.forward_skip(x1)
+        s2, x3 = self.down_3.forward_skip(x2)
+        s3, x4 = self.down_4.forward_skip(x3)
+        u4 = self.upcat_4.forward_act(x4, s3)
+        u3 = self.upcat_3.forward_act(u4, s2)
+        u2 = self.upcat_2.forward_act(u3, s1)
+        u1 = self.upcat_1.forward_act(u2, s0)
         z, _ = self.final_conv.forward_act(u1)
         return z
 

@@ -365,13 +365,21 @@ def maxpool2_fwd(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
-def maxpool2_bwd(x, y, dy) -> torch.Tensor:
+def maxpool2_bwd(x, y, dy, add=None) -> torch.Tensor:
+    """dx of MaxPool3d(2); `add` (same shape as x, possibly a channel slice of a wider buffer) is summed into it"""
     require_cuda(x, y, dy)
     n, d, h, w, c = x.shape
     dx = torch.empty((n, d, h, w, c), dtype=x.dtype, device=x.device)
-    _lib.check(_lib.load().mi355_maxpool2_bwd(x.data_ptr(), act_ld(x), y.data_ptr(), act_ld(y), dy.data_ptr(),
-                                              act_ld(dy), dx.data_ptr(), act_ld(dx), n, c, d, h, w,
-                                              _DT[x.dtype], _stream()), "maxpool2_bwd")
+    if add is None:
+        _lib.check(_lib.load().mi355_maxpool2_bwd(x.data_ptr(), act_ld(x), y.data_ptr(), act_ld(y), dy.data_ptr(),
+                                                  act_ld(dy), dx.data_ptr(), act_ld(dx), n, c, d, h, w,
+                                                  _DT[x.dtype], _stream()), "maxpool2_bwd")
+    else:
+        require_cuda(add)
+        assert add.shape == x.shape and add.dtype == x.dtype
+        _lib.check(_lib.load().mi355_maxpool2_bwd_add(x.data_ptr(), act_ld(x), y.data_ptr(), act_ld(y), dy.data_ptr(),
+                                                      act_ld(dy), dx.data_ptr(), act_ld(dx), add.data_ptr(), act_ld(add),
+                                                      n, c, d, h, w, _DT[x.dtype], _stream()), "maxpool2_bwd_add")
     return dx
 
 
