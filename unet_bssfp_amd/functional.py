@@ -5,6 +5,8 @@ back-propagation through the discriminator into the generator (src/model.py:172,
 with the reference's stock modules."""
 from __future__ import annotations
 
+import os
+import weakref
 from typing import Optional
 
 import torch
@@ -98,6 +100,30 @@ def _padded(vec: Optional[torch.Tensor], n: int, fill: float = 0.0) -> Optional[
 
 
 # ====================================================================================== layout
+class PackMemo:
+    """Packed form of constant NCDHW inputs, valid within ONE training step (``clear()`` runs at the start of every
+    step, so a benchmark that feeds the same batch again still packs it each step).  An entry is tied to the tensor
+    OBJECT (weak reference) and its version counter, never to an address."""
+    _store = {}
+
+    @classmethod
+    def get(cls, x, cp, dtype):
+        e = cls._store.get((id(x), cp, dtype))
+        if e is not None and e[0]() is x and e[1] == x._version:
+            return e[2]
+        return None
+
+    @classmethod
+    def put(cls, x, cp, dtype, act):
+        if len(cls._store) >= 8:
+            cls._store.clear()
+        cls._store[(id(x), cp, dtype)] = (weakref.ref(x), x._version, act)
+
+    @classmethod
+    def clear(cls):
+        cls._store.clear()
+
+
 class PackFn(Function):
     """NCDHW f32 tensors -> one NDHWC activation (virtual torch.cat along channels + layout)."""
 
@@ -397,6 +423,7 @@ class DropoutState:
     def advance(cls, device):
         cls.base(device).add_(1)
         cls._salt = 0
+        PackMemo.clear()                    # a new training step: constant inputs are packed afresh
 
     @classmethod
     def reset(cls):

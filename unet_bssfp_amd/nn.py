@@ -58,7 +58,15 @@ class _Mi355Module(nn.Module):
         if x.dim() != 5:
             raise ValueError(f"expected a 5-D (N,C,D,H,W) tensor, got {tuple(x.shape)}")
         cp = round_up(x.shape[1], 16) if cp is None else cp
-        return Fn.PackFn.apply(cp, self.compute_dtype, x)
+        if x.requires_grad or torch.is_grad_enabled() and x.grad_fn is not None:
+            return Fn.PackFn.apply(cp, self.compute_dtype, x)
+        # a constant input (the batch's x) entering the path more than once in a training step -- generator phase and
+        # discriminator phase -- is packed once; the memo is emptied at the start of every step (Fn.PackMemo)
+        hit = Fn.PackMemo.get(x, cp, self.compute_dtype)
+        if hit is None:
+            hit = Fn.PackFn.apply(cp, self.compute_dtype, x)
+            Fn.PackMemo.put(x, cp, self.compute_dtype, hit)
+        return hit
 
     @staticmethod
     def _from_act(act: torch.Tensor, c: int) -> torch.Tensor:
