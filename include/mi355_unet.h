@@ -187,11 +187,13 @@ int32_t mi355_channel_stats_blocks(int64_t rows_per_group);
 
 /* mean/rstd per (group, channel) from partials (f64 combine).  shift[c] (may be NULL) is added to
  * the mean (conv bias when partials were taken before the bias add).  Optionally updates
- * BatchNorm running stats: rm = (1-mom)*rm + mom*mean, rv = (1-mom)*rv + mom*var*cnt/(cnt-1). */
+ * BatchNorm running stats: rm = (1-mom)*rm + mom*mean, rv = (1-mom)*rv + mom*var*cnt/(cnt-1).
+ * batches_tracked (optional, device int64[1]): BatchNorm's num_batches_tracked, advanced by one.
+ */
 int mi355_norm_finalize(const float* part, int32_t parts_per_group, int32_t groups, int32_t c,
                         int64_t count_per_group, const float* shift, int32_t n_real, float eps,
                         float* mean, float* rstd,
-                        float* running_mean, float* running_var, float momentum, void* stream);
+                        float* running_mean, float* running_var, float momentum, int64_t* batches_tracked, void* stream);
 
 typedef struct mi355_normact_desc {
   const void* z; int32_t ldz;        /* conv output */

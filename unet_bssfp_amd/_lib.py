@@ -74,7 +74,7 @@ _SIGNATURES = {
     "mi355_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc), _vp]),
     "mi355_channel_stats": (C.c_int, [_vp, _i32, _i32, _i64, _i32, _vp, _i32, _i32, _vp]),
     "mi355_channel_stats_blocks": (_i32, [_i64]),
-    "mi355_norm_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i64, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _f32, _vp]),
+    "mi355_norm_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i64, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _f32, _vp, _vp]),
     "mi355_normact_fwd": (C.c_int, [C.POINTER(NormActDesc), _vp]),
     "mi355_normact_bwd_reduce": (C.c_int, [C.POINTER(NormActDesc), _vp]),
     "mi355_normact_bwd_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),

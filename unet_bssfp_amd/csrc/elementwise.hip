@@ -212,9 +212,11 @@ __global__ __launch_bounds__(1024) void norm_finalize_kernel(const float* __rest
                                                              long long count, const float* __restrict__ shift,
                                                              int n_real, float eps, float* __restrict__ mean,
                                                              float* __restrict__ rstd, float* running_mean,
-                                                             float* running_var, float momentum) {
+                                                             float* running_var, float momentum,
+                                                             long long* batches_tracked) {
   const int g = blockIdx.y;
   const int ch0 = blockIdx.x * 8;
+  if (batches_tracked && blockIdx.x == 0 && g == 0 && threadIdx.x == 0) batches_tracked[0] += 1;   // BatchNorm's counter
   double s1, s2;
   block_sum_parts(part + (long long)g * ppg * 2 * c, ppg, c, ch0, s1, s2);
   const int ch = ch0 + (int)threadIdx.x;
@@ -860,11 +862,12 @@ int mi355_channel_stats(const void* x, int32_t ld, int32_t c, int64_t rows_per_g
 
 int mi355_norm_finalize(const float* part, int32_t parts_per_group, int32_t groups, int32_t c, int64_t count_per_group,
                         const float* shift, int32_t n_real, float eps, float* mean, float* rstd, float* running_mean,
-                        float* running_var, float momentum, void* stream) {
+                        float* running_var, float momentum, int64_t* batches_tracked, void* stream) {
   MI355_REQUIRE(part && mean && rstd && parts_per_group > 0 && groups > 0 && c > 0 && count_per_group > 0, "norm_finalize: bad argument");
   MI355_REQUIRE(!running_mean || (running_var && groups == 1), "norm_finalize: running stats need groups == 1");
   hipLaunchKernelGGL(norm_finalize_kernel, dim3((c + 7) / 8, groups), dim3(1024), 0, (hipStream_t)stream, part,
-                     parts_per_group, c, (long long)count_per_group, shift, n_real > 0 ? n_real : c, eps, mean, rstd, running_mean, running_var, momentum);
+                     parts_per_group, c, (long long)count_per_group, shift, n_real > 0 ? n_real : c, eps, mean, rstd, running_mean, running_var, momentum,
+                     (long long*)batches_tracked);
   return mi355_check_launch("norm_finalize");
 }
 

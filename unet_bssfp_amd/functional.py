@@ -436,7 +436,7 @@ class NormActFn(Function):
 
     @staticmethod
     def forward(ctx, z, part, gamma, beta, conv_bias, cfg: NormCfg, training, running_mean, running_var,
-                s2d_out: bool = False):
+                s2d_out: bool = False, batches_tracked=None):
         z = ops.as_act(z)
         n, d, h, w, c = z.shape
         rows = n * d * h * w
@@ -459,7 +459,8 @@ class NormActFn(Function):
                 n_real = running_mean.numel() if upd else (shift.numel() if shift is not None else 0)
                 mean, rstd = ops.norm_finalize(part, ppg, groups, c, rows // groups, shift, cfg.eps,
                                                running_mean if upd else None, running_var if upd else None,
-                                               cfg.momentum, n_real=n_real)
+                                               cfg.momentum, n_real=n_real,
+                                               batches_tracked=batches_tracked if upd else None)
                 batch_stats = True
             else:
                 mean = _padded(running_mean, c).reshape(1, c)
@@ -491,7 +492,7 @@ class NormActFn(Function):
                                             want_affine and mean is not None, s2d=ctx.s2d_out, seed_t=ctx.seed_t)
         dg = dgamma[:nch].contiguous() if (dgamma is not None and ctx.needs_input_grad[2]) else None
         dbt = dbeta[:nch].contiguous() if (dbeta is not None and ctx.needs_input_grad[3]) else None
-        return dz, None, dg, dbt, None, None, None, None, None, None
+        return dz, None, dg, dbt, None, None, None, None, None, None, None
 
 
 # ====================================================================================== pool / loss

@@ -172,11 +172,10 @@ class DownSampleConv(_Mi355Module):
             assert not s2d_out
             return z
         if self.batchnorm:
-            a = Fn.NormActFn.apply(z, part if fuse else None, self.bn.weight, self.bn.bias, self.conv.bias,
-                                   self.cfg, self.training, self.bn.running_mean, self.bn.running_var, s2d_out)
-            if self.training:
-                self.bn.num_batches_tracked += 1
-            return a
+            # num_batches_tracked is advanced by the statistics kernel (no launch of its own)
+            return Fn.NormActFn.apply(z, part if fuse else None, self.bn.weight, self.bn.bias, self.conv.bias,
+                                      self.cfg, self.training, self.bn.running_mean, self.bn.running_var, s2d_out,
+                                      self.bn.num_batches_tracked if self.training else None)
         return Fn.NormActFn.apply(z, None, None, None, None, self.cfg, self.training, None, None, s2d_out)
 
     def forward(self, x):

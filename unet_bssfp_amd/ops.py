@@ -273,13 +273,13 @@ def channel_stats(x: torch.Tensor, groups: int) -> Tuple[torch.Tensor, int]:
 
 
 def norm_finalize(part, parts_per_group, groups, c, count, shift, eps, running_mean=None, running_var=None,
-                  momentum=0.0, n_real=0):
+                  momentum=0.0, n_real=0, batches_tracked=None):
     """n_real: entries of `shift` / the running buffers when they are shorter than the padded channel count c."""
     mean = torch.empty((groups, c), dtype=torch.float32, device=part.device)
     rstd = torch.empty_like(mean)
     _lib.check(_lib.load().mi355_norm_finalize(part.data_ptr(), parts_per_group, groups, c, count, _ptr(shift), n_real,
                                                eps, mean.data_ptr(), rstd.data_ptr(), _ptr(running_mean),
-                                               _ptr(running_var), momentum, _stream()), "norm_finalize")
+                                               _ptr(running_var), momentum, _ptr(batches_tracked), _stream()), "norm_finalize")
     return mean, rstd
 
 
