@@ -50,8 +50,8 @@ PROFILED_TRAFFIC = {("bf16", 128, "gan_step"): 2 * 268627.3e3 + 153600.0e3}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--batch", type=int, default=1, help="volumes per GPU per step")
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
