@@ -178,27 +178,35 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WreduceArgs a) 
 // kernel above scatters 4-byte stores (measured 176 us for 512->512).  Here a block owns all taps of an
 // 8 (ci) x 32 (co) patch, sums the slabs in order (128-B read segments) and turns the patch through LDS so
 // that every output-channel row is written as one contiguous run of 8 * taps floats.
-template <int NT>
+// CIB = input channels per block (8, 4 or 2: fewer when the patch count would not fill the chip); the 8 / CIB
+// thread groups of a channel split the taps.
+template <int NT, int CIB>
 __global__ __launch_bounds__(256) void wgrad_reduce_dense_kernel(const WreduceArgs a) {
-  constexpr int ROW = 8 * NT + 1;
+  constexpr int ROW = CIB * NT + 1, G = 8 / CIB, TPT = (NT + G - 1) / G;
   __shared__ float tile[32 * ROW];
-  const int t = threadIdx.x, co_l = t & 31, ci_l = t >> 5;
-  const int ci0 = blockIdx.x * 8, co0 = blockIdx.y * 32;
+  const int t = threadIdx.x, co_l = t & 31, ci_l = (t >> 5) % CIB, tg = (t >> 5) / CIB;
+  const int ci0 = blockIdx.x * CIB, co0 = blockIdx.y * 32;
   const long long per = (long long)NT * a.cinp * a.coutp;
   const float* base = a.slab + ((long long)(ci0 + ci_l)) * a.coutp + co0 + co_l;
   const long long tstride = (long long)a.cinp * a.coutp;
-  float s[NT];
+  float s[TPT];
 #pragma unroll
-  for (int tap = 0; tap < NT; ++tap) s[tap] = 0.f;
-  for (int k = 0; k < a.nslabs; ++k) {            // slab order fixed => deterministic; NT loads in flight per lane
+  for (int i = 0; i < TPT; ++i) s[i] = 0.f;
+  for (int k = 0; k < a.nslabs; ++k) {            // slab order fixed => deterministic; TPT loads in flight per lane
     const float* p = base + (long long)k * per;
 #pragma unroll
-    for (int tap = 0; tap < NT; ++tap) s[tap] += p[tap * tstride];
+    for (int i = 0; i < TPT; ++i) {
+      const int tap = tg + i * G;
+      if (tap < NT) s[i] += p[tap * tstride];
+    }
   }
 #pragma unroll
-  for (int tap = 0; tap < NT; ++tap) tile[co_l * ROW + ci_l * NT + tap] = s[tap];
+  for (int i = 0; i < TPT; ++i) {
+    const int tap = tg + i * G;
+    if (tap < NT) tile[co_l * ROW + ci_l * NT + tap] = s[i];
+  }
   __syncthreads();
-  const int nci = min(8, a.cin - ci0);            // valid input channels of this patch
+  const int nci = min(CIB, a.cin - ci0);          // valid input channels of this patch
   if (nci <= 0) return;
   const int run = nci * NT;
   for (int r = 0; r < 32; ++r) {
@@ -208,6 +216,52 @@ __global__ __launch_bounds__(256) void wgrad_reduce_dense_kernel(const WreduceAr
     for (int j = t; j < run; j += 256) {
       const float v = tile[r * ROW + j];
       if (a.accumulate) dst[j] += v; else dst[j] = v;
+    }
+  }
+}
+
+// The PatchGAN k4 s2 layers computed on space-to-depth tensors: slab rows are (j, blk * cp + c) with 8 dense
+// taps j and 8 parity blocks blk, and dw[co][c][kd][kh][kw] has kd = 2 jd + bd (likewise h, w): for one (co, c)
+// the 8 x 8 (j, blk) values are the 64 contiguous taps of the 4x4x4 kernel.  The generic kernel scattered them as
+// 4-byte stores (101 us for the 256->512 layer, whose "reduce" has a single slab); here a block turns a
+// 4 (c) x 32 (co) x 64 patch through LDS and writes 256 contiguous floats per output channel.
+__global__ __launch_bounds__(256) void wgrad_reduce_s2d_kernel(const WreduceArgs a) {
+  constexpr int CB = 4, ROW = CB * 64 + 1;
+  __shared__ float tile[32 * ROW];
+  const int t = threadIdx.x, co_l = t & 31, j = t >> 5;                    // j = dense tap of the k2 formulation
+  const int c0 = blockIdx.x * CB, co0 = blockIdx.y * 32;
+  const long long per = (long long)8 * a.cinp * a.coutp;
+  float s[8][CB];
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int c = 0; c < CB; ++c) s[b][c] = 0.f;
+  const float* base = a.slab + ((long long)j * a.cinp + c0) * a.coutp + co0 + co_l;
+  for (int k = 0; k < a.nslabs; ++k) {
+    const float* p = base + (long long)k * per;
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+      for (int c = 0; c < CB; ++c) s[b][c] += p[((long long)b * a.s2d_cp + c) * a.coutp];
+  }
+  const int jd = j >> 2, jh = (j >> 1) & 1, jw = j & 1;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const int tap = (2 * jd + (b >> 2)) * 16 + (2 * jh + ((b >> 1) & 1)) * 4 + (2 * jw + (b & 1));
+#pragma unroll
+    for (int c = 0; c < CB; ++c) tile[co_l * ROW + c * 64 + tap] = s[b][c];
+  }
+  __syncthreads();
+  const int nc = min(CB, a.cin - c0);
+  if (nc <= 0) return;
+  const int run = nc * 64;
+  for (int r = 0; r < 32; ++r) {
+    const int co = co0 + r;
+    if (co >= a.cout) break;
+    float* dst = a.dw + (long long)co * a.s_co + (long long)c0 * a.s_ci;
+    for (int i = t; i < run; i += 256) {
+      const float v = tile[r * ROW + i];
+      if (a.accumulate) dst[i] += v; else dst[i] = v;
     }
   }
 }
@@ -474,10 +528,26 @@ extern "C" int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream) {
   const bool dense = !q.s2d_cp && !q.co_cls && q.s_k2 == 1 && q.s_k1 == d->ks && q.s_k0 == d->ks * d->ks && q.s_ci == k3 &&
                      q.tb0 == 0 && q.tb1 == 0 && q.tb2 == 0 && q.ts0 == 1 && q.ts1 == 1 && q.ts2 == 1;
   if (dense && q.nslabs <= 16 && (d->ks == 3 || d->ks == 1) && q.cinp % 8 == 0 && q.coutp % 32 == 0) {
-    const dim3 grid((unsigned)(q.cinp / 8), (unsigned)(q.coutp / 32));
-    if (d->ks == 3) wgrad_reduce_dense_kernel<27><<<grid, dim3(256), 0, st>>>(q);
-    else wgrad_reduce_dense_kernel<1><<<grid, dim3(256), 0, st>>>(q);
+    // input channels per block: as many as keep >= 512 blocks in flight
+    const long long cob = q.coutp / 32;
+    const int cib = (q.cinp / 8) * cob >= 512 ? 8 : ((q.cinp / 4) * cob >= 512 ? 4 : 2);
+    const dim3 grid((unsigned)(q.cinp / cib), (unsigned)cob);
+#define DENSE(NT)                                                                           \
+    do {                                                                                    \
+      if (cib == 8) wgrad_reduce_dense_kernel<NT, 8><<<grid, dim3(256), 0, st>>>(q);        \
+      else if (cib == 4) wgrad_reduce_dense_kernel<NT, 4><<<grid, dim3(256), 0, st>>>(q);   \
+      else wgrad_reduce_dense_kernel<NT, 2><<<grid, dim3(256), 0, st>>>(q);                 \
+    } while (0)
+    if (d->ks == 3) DENSE(27); else DENSE(1);
+#undef DENSE
     return mi355_check_launch("wgrad_reduce_dense");
+  }
+  const bool s2d_dense = q.s2d_cp > 0 && !q.co_cls && d->ks == 2 && q.s_k2 == 1 && q.s_k1 == 4 && q.s_k0 == 16 && q.s_ci == 64 &&
+                         q.tb0 == 0 && q.tb1 == 0 && q.tb2 == 0 && q.ts0 == 2 && q.ts1 == 2 && q.ts2 == 2 &&
+                         q.cinp == 8 * q.s2d_cp && q.s2d_cp % 4 == 0 && q.coutp % 32 == 0;
+  if (s2d_dense && q.nslabs <= 8) {
+    wgrad_reduce_s2d_kernel<<<dim3((unsigned)(q.s2d_cp / 4), (unsigned)(q.coutp / 32)), dim3(256), 0, st>>>(q);
+    return mi355_check_launch("wgrad_reduce_s2d");
   }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 127) / 128)), dim3(256), 0, st, q);
   return mi355_check_launch("wgrad_reduce");
