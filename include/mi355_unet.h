@@ -66,6 +66,13 @@ int mi355_unpack_ncdhw(const void* src, float* dst, int32_t n, int32_t c, int64_
  * pack:  writes channels [coff, coff+c) (zeros up to zero_to) of every block;  unpack: reads them. */
 int mi355_pack_ncdhw_s2d(const float* src, void* dst, int32_t n, int32_t c, int32_t d, int32_t h, int32_t w,
                          int32_t cblk, int32_t ld, int32_t coff, int32_t zero_to, int32_t dtype, void* stream);
+/* two sources in one pass: channels [coff, coff+c0) <- src0, [coff+c0, coff+c0+c1) <- src1, the rest of the
+ * window up to zero_to <- 0: `torch.cat([x, y], 1)` of the discriminator (src/model.py:86) written as whole rows */
+int mi355_pack2_ncdhw(const float* src0, int32_t c0, const float* src1, int32_t c1, void* dst, int32_t n, int64_t v,
+                      int32_t ld, int32_t coff, int32_t zero_to, int32_t dtype, void* stream);
+int mi355_pack2_ncdhw_s2d(const float* src0, int32_t c0, const float* src1, int32_t c1, void* dst, int32_t n, int32_t d,
+                          int32_t h, int32_t w, int32_t cblk, int32_t ld, int32_t coff, int32_t zero_to, int32_t dtype,
+                          void* stream);
 int mi355_unpack_ncdhw_s2d(const void* src, float* dst, int32_t n, int32_t c, int32_t d, int32_t h, int32_t w,
                            int32_t cblk, int32_t ld, int32_t coff, int32_t dtype, void* stream);
 

@@ -477,3 +477,21 @@ def test_skip_pool_sums_both_gradients_in_the_pool_backward(hip, dtype):
     x2 = x.clone().requires_grad_(True)
     (F.max_pool3d(x2, 2) * gp).sum().backward()
     torch.testing.assert_close(from_act(a2.grad, 32), x2.grad, **TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_two_source_pack_equals_two_single_packs(hip, dtype):
+    """mi355_pack2_ncdhw(_s2d): torch.cat([x, y], 1) in one pass == the two single-source packs, plain and S() layout"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    x, y = torch.rand(2, 24, 4, 6, 8, generator=g).to(DEV), torch.rand(2, 6, 4, 6, 8, generator=g).to(DEV)
+    a = ops.new_act(2, 4, 6, 8, 32, dtype, DEV); a.fill_(7)
+    b = ops.new_act(2, 4, 6, 8, 32, dtype, DEV); b.fill_(7)
+    ops.pack_ncdhw(x, a, 0, 24); ops.pack_ncdhw(y, a, 24, 32)
+    ops.pack2(x, y, b, 0, 32)
+    assert torch.equal(a, b)
+    sa = torch.zeros(ops.s2d_shape(2, 4, 6, 8, 32), dtype=dtype, device=DEV)
+    sb = torch.zeros_like(sa)
+    ops.pack_ncdhw_s2d(x, sa, 32, 0, 24); ops.pack_ncdhw_s2d(y, sa, 32, 24, 32)
+    ops.pack2(x, y, sb, 0, 32, s2d_cblk=32)
+    assert torch.equal(sa, sb)

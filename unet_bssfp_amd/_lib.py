@@ -64,6 +64,8 @@ _SIGNATURES = {
     "mi355_unpack_ncdhw": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _i32, _vp]),
     "mi355_pack_ncdhw_s2d": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mi355_unpack_ncdhw_s2d": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mi355_pack2_ncdhw": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "mi355_pack2_ncdhw_s2d": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mi355_weight_pack": (C.c_int, [C.POINTER(WpackDesc), _vp]),
     "mi355_weight_pack_multi": (C.c_int, [C.POINTER(WpackDesc), _i32, _vp]),
     "mi355_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), _vp]),

@@ -22,21 +22,25 @@ __device__ __forceinline__ long long s2d_offset(const S2D& q, long long row /* n
 }
 
 // ------------------------------------------------------------------ pack / unpack
+// Optional second source: channels [c, c + c1) of the window come from src1 (torch.cat([x, y], 1) of the
+// discriminator as ONE pass that writes whole rows; two single-source passes wrote 48 and 16 of every 64 bytes).
 template <typename T>
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src, T* __restrict__ dst, int c,
-                                                    long long v, int ld, int coff, int zero_to, S2D q) {
+                                                    long long v, int ld, int coff, int zero_to, S2D q,
+                                                    const float* __restrict__ src1, int c1) {
   constexpr int EPV = Elem<T>::kPer16B;
   const long long vox = (long long)blockIdx.x * 256 + threadIdx.x;
   const int n = blockIdx.y;
   if (vox >= v) return;
   const float* s = src + (long long)n * c * v + vox;
+  const float* s1 = src1 ? src1 + (long long)n * c1 * v + vox : nullptr;
   T* drow = q.d ? dst + s2d_offset(q, (long long)n * v + vox, ld) : dst + ((long long)n * v + vox) * ld;
   for (int e0 = coff; e0 < zero_to; e0 += EPV) {
     Vec16<T> o;
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
       const int ch = e0 + j - coff;
-      o.f[j] = ch < c ? s[(long long)ch * v] : 0.f;
+      o.f[j] = ch < c ? s[(long long)ch * v] : ((s1 && ch < c + c1) ? s1[(long long)(ch - c) * v] : 0.f);
     }
     o.store(drow + e0);
   }
@@ -649,17 +653,17 @@ int check_rows(int c, int ld, int dtype, const char* who) {
 extern "C" {
 
 static int pack_impl(const float* src, void* dst, int32_t n, int32_t c, int64_t v, int32_t ld, int32_t coff,
-                     int32_t zero_to, int32_t dtype, S2D q, void* stream) {
-  MI355_REQUIRE(src && dst && n > 0 && c > 0 && v > 0, "pack: bad argument");
+                     int32_t zero_to, int32_t dtype, S2D q, void* stream, const float* src1 = nullptr, int32_t c1 = 0) {
+  MI355_REQUIRE(src && dst && n > 0 && c > 0 && v > 0 && c1 >= 0 && (c1 == 0 || src1), "pack: bad argument");
   const int epv = dtype == MI355_DT_F32 ? 4 : 8;
   MI355_REQUIRE(dtype == MI355_DT_F32 || dtype == MI355_DT_BF16, "pack: bad dtype");
-  MI355_REQUIRE(coff % epv == 0 && zero_to <= ld && (zero_to - coff) % epv == 0 && zero_to - coff >= c && ld % epv == 0,
+  MI355_REQUIRE(coff % epv == 0 && zero_to <= ld && (zero_to - coff) % epv == 0 && zero_to - coff >= c + c1 && ld % epv == 0,
                 "pack: channel window [%d,%d) of ld %d must be 16-byte aligned and hold c=%d", coff, zero_to, ld, c);
   dim3 grid((unsigned)((v + 255) / 256), n);
   if (dtype == MI355_DT_F32)
-    hipLaunchKernelGGL(pack_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, c, (long long)v, ld, coff, zero_to, q);
+    hipLaunchKernelGGL(pack_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, c, (long long)v, ld, coff, zero_to, q, src1, c1);
   else
-    hipLaunchKernelGGL(pack_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, c, (long long)v, ld, coff, zero_to, q);
+    hipLaunchKernelGGL(pack_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, c, (long long)v, ld, coff, zero_to, q, src1, c1);
   return mi355_check_launch("pack");
 }
 
@@ -697,6 +701,21 @@ int mi355_pack_ncdhw_s2d(const float* src, void* dst, int32_t n, int32_t c, int3
   if (rc) return rc;
   MI355_REQUIRE(zero_to <= cblk, "pack_s2d: channel window exceeds the block");
   return pack_impl(src, dst, n, c, (int64_t)d * h * w, ld, coff, zero_to, dtype, S2D{d, h, w, cblk}, stream);
+}
+
+int mi355_pack2_ncdhw(const float* src0, int32_t c0, const float* src1, int32_t c1, void* dst, int32_t n, int64_t v,
+                      int32_t ld, int32_t coff, int32_t zero_to, int32_t dtype, void* stream) {
+  MI355_REQUIRE(src1 && c1 > 0, "pack2: second source missing");
+  return pack_impl(src0, dst, n, c0, v, ld, coff, zero_to, dtype, S2D{0, 0, 0, 0}, stream, src1, c1);
+}
+
+int mi355_pack2_ncdhw_s2d(const float* src0, int32_t c0, const float* src1, int32_t c1, void* dst, int32_t n, int32_t d,
+                          int32_t h, int32_t w, int32_t cblk, int32_t ld, int32_t coff, int32_t zero_to, int32_t dtype,
+                          void* stream) {
+  int rc = check_s2d(d, h, w, cblk, ld, "pack2_s2d");
+  if (rc) return rc;
+  MI355_REQUIRE(src1 && c1 > 0 && zero_to <= cblk, "pack2_s2d: bad argument");
+  return pack_impl(src0, dst, n, c0, (int64_t)d * h * w, ld, coff, zero_to, dtype, S2D{d, h, w, cblk}, stream, src1, c1);
 }
 
 int mi355_unpack_ncdhw_s2d(const void* src, float* dst, int32_t n, int32_t c, int32_t d, int32_t h, int32_t w,

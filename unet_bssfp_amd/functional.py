@@ -145,6 +145,12 @@ class PackFn(Function):
         else:
             out = ops.new_act(n, d, h, w, cp, dtype, srcs[0].device)
         offs, off = [], 0
+        if len(srcs) == 2:
+            # torch.cat([x, y], 1) of the discriminator: both sources in one pass that writes whole rows
+            s0, s1 = (t.detach().to(torch.float32).contiguous() for t in srcs)
+            ops.pack2(s0, s1, out, 0, cp, s2d_cblk=cp if s2d else 0)
+            ctx.offs = [(0, s0.shape[1]), (s0.shape[1], s1.shape[1])]
+            return out
         for i, s in enumerate(srcs):
             c = s.shape[1]
             last = i == len(srcs) - 1

@@ -108,6 +108,24 @@ def pack_ncdhw_s2d(src: torch.Tensor, dst: torch.Tensor, cblk: int, coff: int, z
                                                 zero_to, _DT[dst.dtype], _stream()), "pack_ncdhw_s2d")
 
 
+def pack2(src0: torch.Tensor, src1: torch.Tensor, dst: torch.Tensor, coff: int, zero_to: int, s2d_cblk: int = 0):
+    """torch.cat([src0, src1], 1) packed in ONE pass (whole rows): channels coff.. <- src0 then src1, zeros up to
+    zero_to; s2d_cblk > 0: dst is the (pre-zeroed) space-to-depth tensor with that many channels per block."""
+    require_cuda(src0, src1, dst)
+    for t in (src0, src1):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 5
+    assert src0.shape[0] == src1.shape[0] and src0.shape[2:] == src1.shape[2:]
+    n, c0, d, h, w = src0.shape
+    c1 = src1.shape[1]
+    lib = _lib.load()
+    if s2d_cblk:
+        _lib.check(lib.mi355_pack2_ncdhw_s2d(src0.data_ptr(), c0, src1.data_ptr(), c1, dst.data_ptr(), n, d, h, w, s2d_cblk,
+                                             act_ld(dst), coff, zero_to, _DT[dst.dtype], _stream()), "pack2_ncdhw_s2d")
+    else:
+        _lib.check(lib.mi355_pack2_ncdhw(src0.data_ptr(), c0, src1.data_ptr(), c1, dst.data_ptr(), n, d * h * w, act_ld(dst),
+                                         coff, zero_to, _DT[dst.dtype], _stream()), "pack2_ncdhw")
+
+
 def unpack_ncdhw_s2d(src: torch.Tensor, c: int, dims, cblk: int, coff: int = 0) -> torch.Tensor:
     require_cuda(src)
     n = src.shape[0]
