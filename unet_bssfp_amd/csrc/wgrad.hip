@@ -398,8 +398,91 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradArgs a, i
   }
 }
 
+// Transposed-conv (k2 s2) weight gradient, bf16: D[ci][cls * Cout + co] = sum_v x[v][ci] * g[2v + cls][co], one GEMM
+// with 8 * Cout columns.  `wgrad_bf16_kernel<1,..>` staged x once per 32-column tile: for 64->64 at 64^3 that is 16
+// re-reads of x and 2 of g (1.06 GB for 0.3 GB of operands, 256 us).  Here a workgroup owns NCO = 4 consecutive
+// column tiles: the x tile is staged once, the four g tiles (two parity classes) next to it (80 KB of LDS), each
+// wave takes every 4th k-group and feeds one x fragment to four MFMAs.
+constexpr int kDeconvNco = 4;
+__global__ __launch_bounds__(256, 2) void wgrad_deconv_kernel(const WgradArgs a, int tiles_d, int tiles_h, int tiles_w, int ntiles) {
+  constexpr int TD = 2, TH = 4, TW = 32, NCO = kDeconvNco, ROWS = TD * TH * TW, NP = ROWS * 4 / 256, SEGS = TW / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* xs = smem;
+  char* gsm = smem + ROWS * 64;                          // NCO tiles of ROWS x 64 B
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int ci_base = blockIdx.y * 32, co_base0 = blockIdx.z * (32 * NCO);
+  const int cx_lim = a.c0 - ci_base;
+  const int gi = lane & 15;
+  const int lane_off = (8 * h + (gi >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (gi & 3)) * 2;
+  f32x16 acc[NCO];
+#pragma unroll
+  for (int t = 0; t < NCO; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int q = tile;
+    const int tw_i = q % tiles_w; q /= tiles_w;
+    const int th_i = q % tiles_h; q /= tiles_h;
+    const int td_i = q % tiles_d;
+    const int n = q / tiles_d;
+    const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
+    uint4 sx[NP], sg[NCO][NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = tid + i * 256;
+      const int row = p >> 2, part = p & 3;
+      const int sw = row % TW, sh = (row / TW) % TH, sd = row / (TW * TH);
+      const int gd = d0 + sd, gh = h0 + sh, gw = w0 + sw;
+      const bool in = gd < a.do_ && gh < a.ho && gw < a.wo;
+      sx[i] = (in && part * 8 < cx_lim)
+                  ? *reinterpret_cast<const uint4*>(a.x0 + (((((long long)n * a.di + gd) * a.hi + gh) * a.wi + gw) * (long long)a.ld0 + ci_base + part * 8) * 2)
+                  : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NCO; ++t) {
+        const int co_base = co_base0 + t * 32;
+        const int cls = co_base / a.g_cls_cout, gco = co_base - cls * a.g_cls_cout;
+        const int od = cls >> 2, oh = (cls >> 1) & 1, ow = cls & 1;
+        sg[t][i] = (in && part * 8 < a.g_cls_cout - gco)
+                       ? *reinterpret_cast<const uint4*>(a.g + (((((long long)n * a.gd + (gd * 2 + od)) * a.gh + (gh * 2 + oh)) * a.gw + (gw * 2 + ow)) * (long long)a.ldg + gco + part * 8) * 2)
+                       : make_uint4(0, 0, 0, 0);
+      }
+    }
+    __syncthreads();                      // every wave finished reading the previous tile
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = tid + i * 256;
+      *reinterpret_cast<uint4*>(xs + p * 16) = sx[i];
+#pragma unroll
+      for (int t = 0; t < NCO; ++t) *reinterpret_cast<uint4*>(gsm + t * (ROWS * 64) + p * 16) = sg[t][i];
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int kg = wave; kg < TD * TH * SEGS; kg += 4) {
+      const int off = kg * 16 * 64 + lane_off;            // k-groups are consecutive runs of 16 rows
+      const bf16x8 af = frag_tr(xs + off);
+#pragma unroll
+      for (int t = 0; t < NCO; ++t) {
+        const bf16x8 b = frag_tr(gsm + t * (ROWS * 64) + off);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  float* sl = a.slab + (long long)(blockIdx.x * 4 + wave) * a.cinp * a.coutp;
+#pragma unroll
+  for (int t = 0; t < NCO; ++t) {
+    const int co = co_base0 + t * 32 + r;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int row = ci_base + acc_row(j, h);
+      sl[(long long)row * a.coutp + co] = acc[t][j];
+    }
+  }
+}
+
 struct WPlan { int ks, tpw, tap_groups, ci_tiles, co_tiles, splits, cinp32, coutp32; long long rows;
-               bool fast; int shape, tiles_d, tiles_h, tiles_w, ntiles, nslabs; };
+               bool fast, deconv4; int shape, tiles_d, tiles_h, tiles_w, ntiles, nslabs; };
 
 const int kWTD[2] = {2, 2}, kWTH[2] = {4, 8}, kWTW[2] = {32, 16};
 
@@ -447,7 +530,10 @@ int wplan(const mi355_wgrad_desc* d, WPlan* p) {
     p->tiles_w = ceil_div(d->wo, kWTW[p->shape]);
     p->ntiles = p->tiles_d * p->tiles_h * p->tiles_w * d->n;
     const int wsl = d->ks == 1 ? 4 : 1;                     // slabs per workgroup
-    long long sp = 512 / ((long long)p->ci_tiles * p->co_tiles);      // ~2 workgroups per CU (256 measured slower)
+    // transposed conv at the wide levels: 4 column tiles per workgroup (wgrad_deconv_kernel)
+    p->deconv4 = cls && p->shape == 0 && p->co_tiles % kDeconvNco == 0 && d->do_ % 2 == 0 && d->ho % 4 == 0 && d->wo % 32 == 0;
+    const long long cot = p->deconv4 ? p->co_tiles / kDeconvNco : p->co_tiles;
+    long long sp = 512 / ((long long)p->ci_tiles * cot);      // ~2 workgroups per CU (256 measured slower)
     if (sp < 1) sp = 1;
     if (sp > p->ntiles) sp = p->ntiles;
     while (sp > 1 && sp * wsl * slab_bytes > (256ll << 20)) sp /= 2;
@@ -498,7 +584,10 @@ extern "C" int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream) {
   a.slab = d->workspace; a.cinp = p.cinp32; a.coutp = p.coutp32;
   a.splits = p.splits; a.tap_groups = p.tap_groups; a.rows = p.rows;
   a.g_cls_cout = d->g_cls_cout;
-  if (p.fast) {
+  if (p.fast && p.deconv4) {
+    const dim3 grid(p.splits, p.ci_tiles, p.co_tiles / kDeconvNco);
+    wgrad_deconv_kernel<<<grid, dim3(256), (1 + kDeconvNco) * 256 * 64, st>>>(a, p.tiles_d, p.tiles_h, p.tiles_w, p.ntiles);
+  } else if (p.fast) {
     dim3 grid(p.splits, p.ci_tiles, p.co_tiles), block(256);
 #define WG_FAST(KS, TD, TH, TW)                                                                   \
   do {                                                                                            \
