@@ -124,24 +124,28 @@ __device__ __forceinline__ float4 ld_once(const float* p) {
   const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
   return make_float4(v.x, v.y, v.z, v.w);
 }
+// F4 float4 groups x SL slab lanes per block (F4 * SL = 256): 32 x 8 for ordinary layers; 8 x 32 when a layer has
+// so few weights (1x1x1 convs: 1024 elements under 2048 slabs) that 128-element blocks would leave 8 blocks.
+template <int F4, int SL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WreduceArgs a) {
-  __shared__ float4 red[8][32];
+  static_assert(F4 * SL == 256, "block shape");
+  __shared__ float4 red[SL][F4];
   const long long per = (long long)a.ntaps * a.cinp * a.coutp;        // multiple of 1024
-  const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const long long idx = ((long long)blockIdx.x * 32 + e) * 4;
+  const int e = threadIdx.x % F4, sl = threadIdx.x / F4;
+  const long long idx = ((long long)blockIdx.x * F4 + e) * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (idx < per) {
     const float* base = a.slab + idx;
     int k = sl;
-    for (; k + 24 < a.nslabs; k += 32) {
+    for (; k + 3 * SL < a.nslabs; k += 4 * SL) {
       const float4 v0 = ld_once(base + (long long)k * per);
-      const float4 v1 = ld_once(base + (long long)(k + 8) * per);
-      const float4 v2 = ld_once(base + (long long)(k + 16) * per);
-      const float4 v3 = ld_once(base + (long long)(k + 24) * per);
+      const float4 v1 = ld_once(base + (long long)(k + SL) * per);
+      const float4 v2 = ld_once(base + (long long)(k + 2 * SL) * per);
+      const float4 v3 = ld_once(base + (long long)(k + 3 * SL) * per);
       s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
       s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
     }
-    for (; k < a.nslabs; k += 8) {
+    for (; k < a.nslabs; k += SL) {
       const float4 v = *reinterpret_cast<const float4*>(base + (long long)k * per);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WreduceArgs a) 
   __syncthreads();
   if (sl != 0 || idx >= per) return;
 #pragma unroll
-  for (int q = 1; q < 8; ++q) {
+  for (int q = 1; q < SL; ++q) {
     const float4 v = red[q][e];
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
@@ -638,6 +642,7 @@ extern "C" int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream) {
     wgrad_reduce_s2d_kernel<<<dim3((unsigned)(q.s2d_cp / 4), (unsigned)(q.coutp / 32)), dim3(256), 0, st>>>(q);
     return mi355_check_launch("wgrad_reduce_s2d");
   }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 127) / 128)), dim3(256), 0, st, q);
+  if (per <= 16384 && q.nslabs >= 128) wgrad_reduce_kernel<8, 32><<<dim3((unsigned)((per + 31) / 32)), dim3(256), 0, st>>>(q);
+  else wgrad_reduce_kernel<32, 8><<<dim3((unsigned)((per + 127) / 128)), dim3(256), 0, st>>>(q);
   return mi355_check_launch("wgrad_reduce");
 }
