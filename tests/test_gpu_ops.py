@@ -86,6 +86,10 @@ CONV_CASES = [
     ("k1_head", 2, (24,), 24, (4, 4, 8), 1, 1, 0),
     ("k1_final6", 1, (32,), 6, (4, 4, 8), 1, 1, 0),
     ("k1_final1", 2, (512,), 1, (2, 2, 2), 1, 1, 0),
+    # >= 131072 voxels, <= 32 channels either side: the persistent pointwise kernel in bf16
+    ("k1_pointwise_head", 1, (24,), 24, (64, 64, 32), 1, 1, 0),
+    ("k1_pointwise_final", 2, (32,), 6, (32, 64, 32), 1, 1, 0),
+    ("k1_pointwise_ragged", 1, (16,), 32, (64, 64, 33), 1, 1, 0),
 ]
 
 

@@ -206,6 +206,14 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
         }
       } else { HALO_KS(3) }
     } else { HALO_KS(2) }
+  } else if (sizeof(T) == 2 && !d->cls_cout && d->ks == 1 && d->stride == 1 && d->os == 1 && p.vt == 2 && a.nchunks <= 2 && d->c1 == 0 &&
+             d->coutp == 32 && d->ooff[0] == 0 && d->ooff[1] == 0 && d->ooff[2] == 0 && d->dy == d->do_ && d->hy == d->ho && d->wy == d->wo &&
+             d->pad[0] == 0 && d->pad[1] == 0 && d->pad[2] == 0) {
+    // full-resolution 1x1x1 convs with <= 32 channels either side: persistent streaming kernel
+    const int ntiles = (int)p.tiles;
+    const dim3 g1((unsigned)(ntiles < 2048 ? ntiles : 2048));
+    if (a.nchunks == 1) pointwise_conv_kernel<1><<<g1, block, 0, st>>>(a, ntiles);
+    else pointwise_conv_kernel<2><<<g1, block, 0, st>>>(a, ntiles);
   } else if (sizeof(T) == 2 && d->cls_cout && p.vt == 2 && a.nchunks <= 8 && d->c1 == 0 && (d->cstore & 7) == 0) {
     // transposed-conv forward, Cin <= 128: one workgroup per 256 voxels loops over all column blocks
     const dim3 g1((unsigned)p.tiles);

@@ -577,3 +577,63 @@ __global__ __launch_bounds__(256) void deconv_fwd_kernel(const ConvArgs a) {
     conv_epilogue<T, VT, CT>(q, acc, yoff, co_base, blockIdx.x, red, co_store, tpatch);
   }
 }
+
+// ------------------------------------------------------------------------------------------
+// pointwise_conv_kernel: bf16 1x1x1 stride-1 convolution with <= 32 input and <= 32 output channels at full
+// resolution (generator head 24->24, final conv 32->6 and its data gradient): pure HBM streams (64 B in, 32-64 B
+// out per voxel) that the gather kernel ran at half the achievable bandwidth -- one workgroup per 256 voxels, its
+// index arithmetic, weight-fragment loads and dependent A loads exposed per tile.  Here a workgroup walks many
+// tiles: the weight fragments stay in registers for the whole kernel and the next tile's A fragments are in
+// flight while the current tile's MFMAs and stores run.
+// ------------------------------------------------------------------------------------------
+template <int NCH>   // 16-channel chunks of the input (1 or 2)
+__global__ __launch_bounds__(256) void pointwise_conv_kernel(const ConvArgs a, int ntiles) {
+  using T = bf16_t;
+  constexpr int VT = 2, CT = 1;
+  __shared__ float red[4 * CT * 64];
+  __shared__ __attribute__((aligned(16))) char tpatch[4 * 2048];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  Frag<T> b[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) b[c].load(a.wp + ((long long)c * a.coutp + r) * 32 + h * 16);
+  auto load_tile = [&](int tile, Frag<T> (&af)[VT][NCH], long long (&m)[VT]) {
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt) {
+      m[vt] = (long long)tile * (128 * VT) + (wave * VT + vt) * 32 + r;
+      const bool ok = m[vt] < a.m_total;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if (ok) af[vt][c].load(a.x0 + (m[vt] * a.ld0 + c * 16) * 2 + h * 16);
+        else af[vt][c].zero();
+      }
+      if (!ok) m[vt] = -1;
+    }
+  };
+  Frag<T> cur[VT][NCH], nxt[VT][NCH];
+  long long mc[VT], mn[VT];
+  int tile = blockIdx.x;
+  if (tile < ntiles) load_tile(tile, cur, mc);
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int tn = tile + gridDim.x;
+    if (tn < ntiles) load_tile(tn, nxt, mn);              // in flight under this tile's MFMAs and stores
+    f32x16 acc[VT][CT];
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[vt][0][i] = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) mma16(cur[vt][c], b[c], acc[vt][0]);
+    }
+    long long yoff[VT];
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt) yoff[vt] = mc[vt] >= 0 ? mc[vt] * a.ldy : -1;
+    conv_epilogue<T, VT, CT>(a, acc, yoff, 0, tile, red, 0, tpatch);
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt) {
+      mc[vt] = mn[vt];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) cur[vt][c] = nxt[vt][c];
+    }
+  }
+}
