@@ -87,6 +87,9 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
       // 32^3-level layers on the plain tile: one 64-channel tile per workgroup leaves <= 1 workgroup per CU on a
       // long K loop; 32-channel tiles double the workgroups (measured 128->64: 40 -> 30 us, 128->128: 48 -> 41 us)
       if (p->shape == 0 && p->ct == 2 && count(0, 2) < 512 && forced_ct() != 2) p->ct = 1;
+      // ... and when even that leaves <= 2 workgroups per CU, half-width tiles (2x4x16, one subtile per wave) double
+      // them again: -0.1 ms per step in the interleaved A/B (256->128 at 32^3: 98 -> 91 us, 128->64: 31 -> 26 us)
+      if (p->shape == 0 && p->ct == 1 && d->ks == 3 && count(0, 1) <= 512) p->shape = 4;
     } else {
       // low levels: few tiles -> favour more, smaller workgroups (the K loop is long, the grid is not)
       if (count(p->shape, p->ct) < 512) p->ct = 1;
