@@ -121,7 +121,7 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
     const long long wgs = p->tiles * (d->coutp / (32 * p->ct));
     const int nchunks = (d->c0 + d->c1) / 16;
     const int fk = forced_ksplit();
-    if ((fk == 0 && ((wgs < 256 && nchunks >= 8) || (wgs < 512 && nchunks >= 16))) || fk > 1) {   // (32^3 x 128 ch measured slower split)
+    if ((fk == 0 && ((wgs < 256 && nchunks >= 8) || (wgs <= 512 && nchunks >= 16))) || fk > 1) {   // (32^3 x 128 ch measured slower split)
       long long ks = (1024 + wgs - 1) / wgs;
       if (fk > 1) ks = fk;
       if (ks > nchunks / 2) ks = nchunks / 2;
