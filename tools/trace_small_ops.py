@@ -1,10 +1,10 @@
-"""Attribute the small torch-native launches of one eager training step to Python call sites (torch.profiler with stacks)."""
-import collections, os, sys
+"""Attribute the small torch launches of one eager training step to Python call sites: wraps a few Tensor methods /
+torch functions and counts (op, caller) pairs (calls made inside the autograd engine's C++ side are not seen)."""
+import collections, os, sys, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import unet_bssfp_amd as M
 from unet_bssfp_amd.gan import bSSFPToDWITensorModel, synthetic_batch
-from torch.profiler import profile, ProfilerActivity
 
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
@@ -14,15 +14,36 @@ batch = synthetic_batch(1, 64, seed=1, device=dev)
 for _ in range(2):
     model.training_step(batch)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True) as prof:
-    model.training_step(batch)
-torch.cuda.synchronize()
-want = ("aten::fill_", "aten::zero_", "aten::copy_", "aten::add", "aten::add_", "aten::zeros", "aten::full", "aten::contiguous", "aten::clone")
 cnt = collections.Counter()
-for ev in prof.events():
-    if ev.name in want:
-        st = [s for s in ev.stack if "unet_bssfp_amd" in s or "bench" in s or "autograd" in s.lower()]
-        key = (ev.name, st[0] if st else (ev.stack[0] if ev.stack else "?"), str(ev.input_shapes)[:60])
-        cnt[key] += 1
-for (name, where, shp), n in cnt.most_common(60):
-    print(f"{n:4d} {name:18s} {where[-90:]:90s} {shp}")
+ACTIVE = [False]
+
+
+def site():
+    for fr in reversed(traceback.extract_stack()[:-2]):
+        if "unet_bssfp_amd" in fr.filename or "optim" in fr.filename:
+            return f"{os.path.basename(fr.filename)}:{fr.lineno}"
+    return "?"
+
+
+def wrap(owner, name):
+    orig = getattr(owner, name)
+
+    def f(*a, **k):
+        if ACTIVE[0]:
+            t = a[0] if a and isinstance(a[0], torch.Tensor) else None
+            shp = tuple(t.shape) if t is not None else (a[0] if a else None)
+            cnt[(f"{getattr(owner, '__name__', owner)}.{name}", site(), str(shp)[:40])] += 1
+        return orig(*a, **k)
+    setattr(owner, name, f)
+
+
+for nm in ("copy_", "add_", "zero_", "fill_", "contiguous", "clone", "mul_", "float", "to", "__add__", "__iadd__", "__mul__", "__truediv__", "sum", "mean"):
+    wrap(torch.Tensor, nm)
+for nm in ("zeros", "ones_like", "zeros_like", "full", "stack", "cat", "empty_like"):
+    wrap(torch, nm)
+ACTIVE[0] = True
+model.training_step(batch)
+ACTIVE[0] = False
+torch.cuda.synchronize()
+for (op, where, shp), n in cnt.most_common(70):
+    print(f"{n:4d} {op:28s} {where:28s} {shp}")
