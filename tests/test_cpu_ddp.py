@@ -59,6 +59,24 @@ def _worker_sync(rank, world, port, q):
                 continue
             avg = sum(ref[r][i] for r in range(world)) / world
             torch.testing.assert_close(mine, avg, rtol=1e-5, atol=1e-7)
+        # gradient accumulation: two backward() calls in one phase -- the second accumulation arrives after some
+        # buckets have already been exchanged; finish() must deliver the average of the SUMMED local gradients
+        net.zero_grad()
+        for rep in range(2):
+            o = net[2](net[1](net[0](xs[rank] * (rep + 1))))
+            o.pow(2).sum().backward()
+        sync.finish()
+        got = [None if p.grad is None else p.grad.detach().clone() for p in net.parameters()]
+        acc = []
+        for r in range(world):
+            net.zero_grad()
+            for rep in range(2):
+                o = net[2](net[1](net[0](xs[r] * (rep + 1))))
+                o.pow(2).sum().backward()
+            acc.append([None if p.grad is None else p.grad.detach().clone() for p in net.parameters()])
+        for i, mine in enumerate(got):
+            if mine is not None:
+                torch.testing.assert_close(mine, sum(acc[r][i] for r in range(world)) / world, rtol=1e-5, atol=1e-7)
         logs = ddp.reduce_logs(torch.tensor([float(rank), 2.0]))
         torch.testing.assert_close(logs, torch.tensor([(world - 1) / 2.0, 2.0]))
         q.put((rank, "ok"))

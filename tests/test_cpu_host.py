@@ -112,7 +112,7 @@ def test_gan_harness_with_oracle_modules_matches_oracle_step():
         model.training_step(batch, step)
         ref = R.gan_training_step(g2, d2, g_opt, d_opt, x, y)
         for k in ("gen_loss_adversarial", "gen_loss_recon_L1", "gen_loss_recon", "gen_loss", "discr_loss"):
-            assert float(model.last_logs[k]) == pytest.approx(float(ref[k]), rel=1e-6), (step, k)
+            assert float(model.last_logs["train_" + k]) == pytest.approx(float(ref[k]), rel=1e-6), (step, k)   # the reference's log names
     for (n, p), (_, q) in zip(g1.named_parameters(), g2.named_parameters()):
         assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), n
     assert model.stacked_logs().shape == (5,)

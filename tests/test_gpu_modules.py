@@ -197,8 +197,8 @@ def test_gan_training_step_golden(hip, golden_dir):
     discr = M.Discriminator("bssfp")
     model = bSSFPToDWITensorModel("bssfp", gen=gen.to(DEV), discr=discr.to(DEV)).train()
     batch = synthetic_batch(1, 64, seed=1234, device=DEV)
-    names = {"gen_loss_adversarial": "gen_loss_adversarial", "gen_loss_recon_L1": "gen_loss_recon_L1",
-             "gen_loss_recon": "gen_loss_recon", "gen_loss": "gen_loss", "discr_loss": "discr_loss"}
+    names = {"train_gen_loss_adversarial": "gen_loss_adversarial", "train_gen_loss_recon_L1": "gen_loss_recon_L1",
+             "train_gen_loss_recon": "gen_loss_recon", "train_gen_loss": "gen_loss", "train_discr_loss": "discr_loss"}
     def noisy(tag, n):            # zero-gradient biases in front of a norm: AdamW amplifies rounding noise
         if tag == "discr":
             return n in ("d2.conv.bias", "d3.conv.bias", "d4.conv.bias", "d5.conv.bias")
@@ -247,7 +247,7 @@ def test_gan_step_matches_oracle_n2_s64_with_torch_adamw(hip):
         ref = R.gan_training_step(rgen, rdiscr, g_opt, d_opt, x, y)
         for k in ("gen_loss_adversarial", "gen_loss_recon_L1", "gen_loss_recon", "gen_loss", "discr_loss"):
             # step 1 follows an AdamW update (sign-like at t=1): see test_gan_training_step_golden
-            np.testing.assert_allclose(float(model.last_logs[k]), float(ref[k]), rtol=1e-3 if step == 0 else 3e-2,
+            np.testing.assert_allclose(float(model.last_logs["train_" + k]), float(ref[k]), rtol=1e-3 if step == 0 else 3e-2,
                                        err_msg=f"{step}/{k}")
     # BatchNorm buffers advanced identically: head BN twice per step, PatchGAN BN three times per step
     assert int(model.gen.blocks["bssfp"].bn.num_batches_tracked) == int(rgen.blocks["bssfp"].bn.num_batches_tracked) == 4
@@ -377,7 +377,7 @@ def test_config5_size_160_forward_parity_and_step(hip):
     model.training_step(batch)
     logs = {k: float(v) for k, v in model.last_logs.items()}
     assert all(np.isfinite(v) for v in logs.values()), logs
-    assert 0.2 < logs["gen_loss_recon_L1"] < 1.0 and 0.3 < logs["discr_loss"] < 2.0, logs
+    assert 0.2 < logs["train_gen_loss_recon_L1"] < 1.0 and 0.3 < logs["train_discr_loss"] < 2.0, logs
 
 
 def test_hipgraph_replayed_step_equals_eager_step(hip):
@@ -405,7 +405,7 @@ def test_hipgraph_replayed_step_equals_eager_step(hip):
     torch.cuda.synchronize()
     for (n, p), (_, q) in zip(eager.named_parameters(), graphed.named_parameters()):
         assert torch.equal(p, q), n
-    for k in ("gen_loss", "discr_loss"):
+    for k in ("train_gen_loss", "train_discr_loss"):
         assert float(eager.last_logs[k]) == float(graphed.last_logs[k])
     g_opt, _ = graphed.optimizers()
     g_opt.sync_step_counts()

@@ -143,7 +143,7 @@ def test_gpu_test_step_logs_and_sums_patch_losses():
     sampler = I.GridSampler(subject, 64)                          # 2 patches -> one batch of 2
     tot = model.test_step((sampler, I.GridAggregator(sampler), I.GridAggregator(sampler), I.GridAggregator(sampler)))
     logs = {k: float(v) for k, v in model.last_logs.items()}
-    assert {"test_gen_loss_subject", "test_loss_recon_L1", "test_loss_adversarial", "test_metric_PSNR", "test_metric_SSIM",
+    assert {"test_gen_loss_subject", "test_gen_loss_recon_L1", "test_gen_loss_adversarial", "test_metric_PSNR", "test_metric_SSIM",
             "test_metric_L1"} <= set(logs)
     assert float(tot) == pytest.approx(logs["test_gen_loss_subject"]) and np.isfinite(float(tot))
-    assert abs(logs["test_metric_L1"] - logs["test_loss_recon_L1"]) < 5e-3      # overlapping patches: last one wins in the volume
+    assert abs(logs["test_metric_L1"] - logs["test_gen_loss_recon_L1"]) < 5e-3      # overlapping patches: last one wins in the volume

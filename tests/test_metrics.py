@@ -72,8 +72,8 @@ def test_gpu_validation_step_logs_reference_keys():
     x, y = R.synthetic_batch(1, 64, seed=2)
     loss = model.validation_step({"bssfp": {"data": x.cuda()}, "dwi-tensor_orig": {"data": y.cuda()}})
     logs = {k: float(v) for k, v in model.last_logs.items()}
-    assert {"val_loss", "val_loss_recon", "val_loss_recon_L1", "val_loss_adversarial", "val_metric_PSNR", "val_metric_SSIM",
+    assert {"val_loss", "val_gen_loss_recon", "val_gen_loss_recon_L1", "val_gen_loss_adversarial", "val_metric_PSNR", "val_metric_SSIM",
             "val_metric_L1"} <= set(logs)
-    assert abs(logs["val_metric_L1"] - logs["val_loss_recon_L1"]) < 1e-5          # MAE metric == L1 loss term
+    assert abs(logs["val_metric_L1"] - logs["val_gen_loss_recon_L1"]) < 1e-5          # MAE metric == L1 loss term
     assert abs(logs["val_metric_PSNR"] + 10 * math.log10(max(logs["val_metric_L1"] ** 2, 1e-12))) < 6   # same order as -10 log10(mse)
     assert -1.0 <= logs["val_metric_SSIM"] <= 1.0 and float(loss) == pytest.approx(logs["val_loss"])

@@ -9,8 +9,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# MI355_LIB: load another build of the same ABI (A/B runs of two kernel versions inside one gpurun call)
-LIB_PATH = os.environ.get("MI355_LIB") or os.path.join(_HERE, "libmi355_unet.so")
+LIB_PATH = os.path.join(_HERE, "libmi355_unet.so")   # the one shipped build; no environment override (tools/diaglib.py swaps it for A/B runs)
 
 DT_F32 = 0
 DT_BF16 = 1

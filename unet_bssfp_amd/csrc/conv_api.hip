@@ -26,16 +26,18 @@ int gcd_i(long long a, long long b) { while (b) { long long t = a % b; a = b; b 
 const int kTD[10] = {2, 2, 4, 4, 2, 2, 4, 8, 4, 4}, kTH[10] = {4, 8, 8, 4, 4, 8, 4, 4, 4, 4}, kTW[10] = {32, 16, 8, 32, 16, 8, 32, 32, 32, 32},
           kVT[10] = {2, 2, 2, 4, 1, 1, 2, 4, 4, 4};
 
+// Plan overrides for A/B runs exist only in the diagnostic build (-DMI355_DIAG, built by tools/build_diag.sh into
+// tools/_build/, never shipped): MI355_CONV_SHAPE=<0|6|9|10>, MI355_CONV_CT=<1|2>, MI355_CONV_KSPLIT=<n>.
+#ifdef MI355_DIAG
 int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-// plan experiments (A/B in one process each): MI355_CONV_CT=<1|2> forces the Cout tiles per workgroup of halo plans,
-// MI355_CONV_KSPLIT=<n> forces the split-K factor (1 = off) where a split is legal
 int forced_ct() { static const int v = env_int("MI355_CONV_CT", 0); return v; }
 int forced_ksplit() { static const int v = env_int("MI355_CONV_KSPLIT", 0); return v; }
-
-int forced_shape() {      // A/B knob, see make_plan
-  static const int v = [] { const char* e = getenv("MI355_CONV_SHAPE"); return e ? atoi(e) : -1; }();
-  return v;
-}
+int forced_shape() { static const int v = env_int("MI355_CONV_SHAPE", -1); return v; }
+#else
+constexpr int forced_ct() { return 0; }
+constexpr int forced_ksplit() { return 0; }
+constexpr int forced_shape() { return -1; }
+#endif
 
 int make_plan(const mi355_conv_desc* d, Plan* p) {
   MI355_REQUIRE(d && d->x0 && d->wp && d->y, "conv: null pointer");
@@ -71,7 +73,7 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
     if (p->shape == 0) {
       if (d->dtype == MI355_DT_BF16 && d->ks == 3) {
         // wide bf16 3x3x3 layers: the row-reuse + LDS-DMA kernel (shape 9) when its 4x4x32 tiles fill the chip,
-        // else 8-wave 4x4x32 tiles (shape 6) / the plain 2x4x32 tile.  MI355_CONV_SHAPE=<0|6|9> forces a choice (A/B).
+        // else 8-wave 4x4x32 tiles (shape 6) / the plain 2x4x32 tile.
         const int f = forced_shape();
         const long long nv = (long long)d->n * d->di * d->hi * d->wi;
         const bool ru_ok = nv * d->ld0 * 2 < (1ll << 31) && nv * (d->c1 ? d->ld1 : 0) * 2 < (1ll << 31);   // 32-bit byte offsets
@@ -163,10 +165,6 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
   a.cls_cout = d->cls_cout;
   a.nbias = d->nbias > 0 ? d->nbias : d->coutp;
   a.kslab = (float*)d->workspace;
-  {
-    static const int abl = [] { const char* e = getenv("MI355_CONV_ABLATE"); return e ? atoi(e) : 0; }();
-    a.ablate = abl;
-  }
   if (p.ksplit > 1) {
     const long long need = (long long)p.ksplit * a.m_total * d->coutp * 4;
     MI355_REQUIRE(d->workspace && d->workspace_bytes >= need, "conv: split-K workspace too small (%lld < %lld)",

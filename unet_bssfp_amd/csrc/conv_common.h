@@ -21,7 +21,6 @@ struct ConvArgs {
   float* kslab;                    // [ksplit][n*do*ho*wo][coutp] f32 partial sums
   int cls_cout;                    // gather kernel: transposed-conv classes folded into the cout index (0 = off)
   int nbias;                       // entries of bias
-  int ablate;                      // timing-only diagnostics (MI355_CONV_ABLATE): 1 no halo loads, 2 no output stores, 4 no weight loads
 };
 
 // Epilogue shared by both kernels.
@@ -70,7 +69,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[V
             const int olo = __shfl(lo, vrow, 64), ohi = __shfl(hi, vrow, 64);
             const long long off = ((long long)ohi << 32) | (unsigned int)olo;
             const uint4 val = *reinterpret_cast<const uint4*>(wbuf + vrow * 64 + (lane & 3) * 16);
-            if (off >= 0 && co0 + 8 <= a.cstore && !(a.ablate & 2)) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(a.y) + off + co0) = val;
+            if (off >= 0 && co0 + 8 <= a.cstore) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(a.y) + off + co0) = val;
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -158,11 +157,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, f32x16 (&a
     bias[ct] = (a.bias && co < a.nbias) ? a.bias[co] : 0.f;
     yp[ct] = co < a.cstore ? reinterpret_cast<T*>(a.y) + co : nullptr;
   }
-#ifdef MI355_NARROW_STORE
-  if constexpr (false) {
-#else
   if constexpr (sizeof(T) == 2) {
-#endif
     // 16-bit outputs: a lane owns ONE channel of 16 voxels, so direct stores would be 2 bytes per lane
     // (32 store instructions per subtile, store-issue bound).  Transpose each 32x32 tile through a
     // wave-private LDS patch and write 16 bytes per lane: 2 store instructions per tile, whole 64-B rows.
@@ -188,7 +183,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, f32x16 (&a
           const int v = pass * 16 + (lane >> 2);
           const int rh = v / TW, cw = v % TW;
           const uint4 val = *reinterpret_cast<const uint4*>(wbuf + v * 64 + (lane & 3) * 16);
-          if (to.dvalid[vt] && rh < to.hleft[vt] && cw < to.wleft[vt] && co0 + 8 <= a.cstore && !(a.ablate & 2))
+          if (to.dvalid[vt] && rh < to.hleft[vt] && cw < to.wleft[vt] && co0 + 8 <= a.cstore)
             *reinterpret_cast<uint4*>(reinterpret_cast<T*>(a.y) + to.base[vt] + rh * to.hstride + cw * to.wstride + co0) = val;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the patch is overwritten

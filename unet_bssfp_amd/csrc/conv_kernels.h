@@ -78,14 +78,10 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && CT == 2 && NW == 4) ? 3
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int part = (tid + i * NTHR) % PPV;
-#ifdef MI355_EXPERIMENT_NO_STAGE
-      stage[i] = make_uint4(gvox[i], part, cbase, (int)ld);
-#else
       if (gvox[i] >= 0)   // (a non-temporal load here was measured slower: halo overlap re-reads then miss L2)
         stage[i] = *reinterpret_cast<const uint4*>(src + ((long long)gvox[i] * ld + cbase) * ES + part * 16);
       else
         stage[i] = make_uint4(0, 0, 0, 0);
-#endif
     }
   };
   auto store_chunk = [&]() {
@@ -130,9 +126,6 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && CT == 2 && NW == 4) ? 3
     // weight fragments are fetched PG taps at a time (all loads of a group in flight together);
     // the group size was measured irrelevant (3 / 9 / 27): the L2-resident weights are not the limiter
     constexpr int PG = (ES == 2) ? (KS == 3 ? 9 : NTAP) : KS;
-#ifdef MI355_EXPERIMENT_NO_MMA
-    if (a.nchunks > 100000)
-#endif
 #pragma unroll
     for (int g0 = 0; g0 < NTAP; g0 += PG) {
       Frag<T> b[PG][CT];
@@ -324,7 +317,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvArgs a) {
 #pragma unroll
       for (int vt = 0; vt < VT; ++vt) {
         Frag<T> af;
-        if (vox[vt] >= 0 && !(a.ablate & 1)) af.load(src + (vox[vt] * ld + cbase) * ES + h * 16);
+        if (vox[vt] >= 0) af.load(src + (vox[vt] * ld + cbase) * ES + h * 16);
         else af.zero();
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) mma16(af, b[ct], acc[vt][ct]);
@@ -443,7 +436,7 @@ __global__ __launch_bounds__(256, CT == 1 ? 4 : 2) void conv_ru_kernel(const Con
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int id = i * NW + wave;
-      if (id < 2 * kRuBlocks && !(a.ablate & 1)) {   // wave-uniform
+      if (id < 2 * kRuBlocks) {   // wave-uniform
         const int off = gvox[i] >= 0 ? gvox[i] * ld2 + coff : (int)0x80000000;   // out of range -> zeros land in LDS
         lds_ptr dst = (lds_ptr)(smem + (id & 1) * kRuPlane + (id >> 1) * 1024);
         if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, off, 0, 0, 0);
@@ -467,7 +460,7 @@ __global__ __launch_bounds__(256, CT == 1 ? 4 : 2) void conv_ru_kernel(const Con
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) b[kh][ct] = bn[kh][ct];
-      if (it < 8 && !(a.ablate & 4)) {
+      if (it < 8) {
         const int nd = (it + 1) / 3, nw = (it + 1) - nd * 3;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)

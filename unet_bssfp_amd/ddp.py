@@ -5,7 +5,8 @@ grad-ready hooks so that it overlaps the remaining backward kernels.
 Replaces what Lightning's ``'ddp_find_unused_parameters_true'`` strategy did implicitly for the
 reference (src/train.py:30): gradient averaging per phase, initial parameter
 broadcast, BatchNorm-buffer broadcast from rank 0, and the six ``sync_dist`` scalar logs (here:
-one reduce).  BatchNorm statistics stay per-rank, as in the reference (no SyncBatchNorm).
+one reduce).  BatchNorm statistics are computed per rank, as in the reference (no SyncBatchNorm); the running
+buffers follow DDP's ``broadcast_buffers=True`` through ``broadcast_buffers()`` (rank 0's values, every ``k`` steps).
 
 Buckets are static and filled in reverse parameter order (decoder gradients are ready first).
 Parameters that receive no gradient in a phase (the unused modality heads; a frozen network)
@@ -33,6 +34,7 @@ class _Bucket:
         self.ready = 0
         self.filled = [False] * len(params)
         self.work = None
+        self.redo = False          # a gradient was accumulated again after the bucket had been exchanged
 
 
 class GradSync:
@@ -71,9 +73,17 @@ class GradSync:
         b, i = self._where[id(p)]
         if b.flat is None or b.flat.device != p.device:
             b.flat = torch.zeros(b.numel, dtype=torch.float32, device=p.device)
-        if b.filled[i]:
-            return  # second accumulation into the same grad in one phase: reduced at finish()
         view = b.flat[b.offsets[i]: b.offsets[i] + p.numel()]
+        if b.filled[i]:
+            # a second backward() accumulated into this .grad within the phase (gradient accumulation): p.grad holds the
+            # running LOCAL sum.  Not yet exchanged: refresh the copy.  Already exchanged: the buffer holds cross-rank sums,
+            # so the whole bucket is rebuilt from the local .grad values and exchanged again at finish().
+            if b.work is not None:
+                b.work.wait()
+                b.work, b.redo = None, True
+            elif not b.redo:
+                view.copy_(p.grad.reshape(-1))
+            return
         view.copy_(p.grad.reshape(-1))
         b.filled[i] = True
         b.ready += 1
@@ -91,10 +101,13 @@ class GradSync:
         for b in self.buckets:
             if b.ready == 0:
                 continue
-            if b.work is None:                    # partially filled: zero the holes, reduce now
+            if b.work is None:                    # partially filled (or to be redone): zero the holes, reduce now
                 for i, p in enumerate(b.params):
+                    view = b.flat[b.offsets[i]: b.offsets[i] + p.numel()]
                     if not b.filled[i]:
-                        b.flat[b.offsets[i]: b.offsets[i] + p.numel()].zero_()
+                        view.zero_()
+                    elif b.redo:
+                        view.copy_(p.grad.reshape(-1))
                 self._launch(b)
         inv = 1.0 / self.world
         for b in self.buckets:
@@ -105,7 +118,7 @@ class GradSync:
             for i, p in enumerate(b.params):
                 if b.filled[i]:
                     p.grad = b.flat[b.offsets[i]: b.offsets[i] + p.numel()].view_as(p)
-            b.work, b.ready, b.filled = None, 0, [False] * len(b.params)
+            b.work, b.ready, b.filled, b.redo = None, 0, [False] * len(b.params), False
             b.flat = None                         # grads alias the buffer until zero_grad(); next phase gets a new one
 
     def remove(self):

@@ -27,14 +27,17 @@ import torch.nn.functional as F
 
 DATA = "data"  # tio.DATA
 
-LOG_KEYS = ("gen_loss_adversarial", "gen_loss_recon_L1", "gen_loss_recon", "gen_loss", "discr_loss")
+# the reference's log names (src/model.py:177, 204-210, 266, 276): EarlyStopping monitors 'val_gen_loss_recon' (src/train.py:19)
+LOG_KEYS = ("train_gen_loss_adversarial", "train_gen_loss_recon_L1", "train_gen_loss_recon", "train_gen_loss",
+            "train_discr_loss")
 
 
 class bSSFPToDWITensorModel(nn.Module):
     def __init__(self, input_modality, lr=1e-3, batch_size=8, perceptual_factor=1e3, recon_factor=1e2,
                  gen: Optional[nn.Module] = None, discr: Optional[nn.Module] = None,
                  l1_fn: Optional[Callable] = None, optimizer_class=None,
-                 extra_recon_terms: Optional[Dict[str, Callable]] = None):
+                 extra_recon_terms: Optional[Dict[str, Callable]] = None, recon_divisor: Optional[int] = None,
+                 reference_quirks: bool = False):
         super().__init__()
         self.input_modality = input_modality
         if gen is None or discr is None:
@@ -47,6 +50,13 @@ class bSSFPToDWITensorModel(nn.Module):
         self.l1_fn = l1_fn
         self.extra_recon_terms = extra_recon_terms or {}
         self.optimizer_class = optimizer_class
+        # src/model.py:209 divides the summed terms by their NUMBER (L1 and Perceptual: 2).  None = the number of terms
+        # present here (1 without the Perceptual slot: recon = 100 * L1); 2 reproduces the reference's weighting of the
+        # L1 term (50 * L1) while the Perceptual term is absent.
+        self.recon_divisor = recon_divisor
+        # True: test_step feeds compute_metrics what the reference feeds it (src/model.py:303-307: the aggregated INPUT
+        # volume under the name pred_tensor) instead of the aggregated prediction
+        self.reference_quirks = reference_quirks
         self.grad_sync_gen = None      # set by ddp.attach(); called after each phase's backward
         self.grad_sync_discr = None
         self._optimizers = None
@@ -89,16 +99,16 @@ class bSSFPToDWITensorModel(nn.Module):
         for name, t in terms.items():
             logs[f"{prefix}_loss_recon_{name}"] = t.detach()
             total = t if total is None else total + t
-        total = total / len(terms) * self.recon_factor
+        total = total / (self.recon_divisor or len(terms)) * self.recon_factor
         logs[f"{prefix}_loss_recon"] = total.detach()
         return total
 
-    def _gen_step(self, x, y, logs, prefix="gen"):
+    def _gen_step(self, x, y, logs, step_name="train"):
         y_hat = self.gen(x)
         logits = self.discr(x, y_hat)
         adv = F.binary_cross_entropy_with_logits(logits, torch.ones_like(logits))
-        recon = self.compute_recon_loss(y_hat, y, logs, prefix)
-        logs[f"{prefix}_loss_adversarial"] = adv.detach()
+        recon = self.compute_recon_loss(y_hat, y, logs, step_name + "_gen")
+        logs[f"{step_name}_gen_loss_adversarial"] = adv.detach()
         return adv + recon, y_hat
 
     def _discr_step(self, x, y):
@@ -131,7 +141,7 @@ class bSSFPToDWITensorModel(nn.Module):
             DropoutState.advance(x.device)
         self._toggle(self.discr, False)
         loss, _ = self._gen_step(x, y, logs)
-        logs["gen_loss"] = loss.detach()
+        logs["train_gen_loss"] = loss.detach()
         loss.backward()
 
     def _phase_gen_update_discr(self, batch, logs):
@@ -144,7 +154,7 @@ class bSSFPToDWITensorModel(nn.Module):
         self._toggle(self.discr, True)
         self._toggle(self.gen, False)
         loss = self._discr_step(x, y)
-        logs["discr_loss"] = loss.detach()
+        logs["train_discr_loss"] = loss.detach()
         loss.backward()
 
     def _phase_discr_update(self):
@@ -213,8 +223,10 @@ class bSSFPToDWITensorModel(nn.Module):
     def test_step(self, batch, batch_idx=0):
         """src/model.py:291-312: the grid loop of ``predict_step`` with ``_gen_step(x, y, 'test')`` per patch batch,
         the summed generator loss logged as ``test_gen_loss_subject`` and the metrics computed on the aggregated
-        volumes.  (The reference passes its mislabelled ``pred_tensor`` -- the aggregated INPUT -- to
-        ``compute_metrics``; here the metrics compare the aggregated prediction with the aggregated target.)"""
+        volumes.  The reference passes its mislabelled ``pred_tensor`` -- the aggregated INPUT -- to
+        ``compute_metrics`` (src/model.py:303-307); ``reference_quirks=True`` reproduces exactly that (it needs as many
+        input as target channels, or metric functions that accept the mismatch, as in the reference); the default compares
+        the aggregated prediction with the aggregated target."""
         from .inference import LOCATION
         sampler, i_agg, t_agg, o_agg = batch
         logs: Dict[str, torch.Tensor] = {}
@@ -228,6 +240,8 @@ class bSSFPToDWITensorModel(nn.Module):
             t_agg.add_batch(y, loc)
             o_agg.add_batch(x, loc)
         y_hat_vol, y_vol = i_agg.get_output_tensor(), t_agg.get_output_tensor()
+        if self.reference_quirks:
+            y_hat_vol = o_agg.get_output_tensor()           # what the reference calls pred_tensor
         self.compute_metrics(y_hat_vol.unsqueeze(0), y_vol.unsqueeze(0), "test", logs)
         logs["test_gen_loss_subject"] = tot_loss
         self.last_logs = logs
