@@ -174,6 +174,35 @@ def case_gan_step(ref, out_dir):
     np.savez_compressed(os.path.join(out_dir, "gan_step.npz"), **store)
 
 
+def case_gan_step_f64(ref, out_dir):
+    """The same two training steps as ``case_gan_step`` in float64 (identical f32 initial weights and inputs, converted):
+    the yard-stick that tells rounding noise from error.  The GPU tests require the f32 HIP path to stay within a small
+    multiple of the distance the CPU f32 run (gan_step.npz) itself keeps from these values, quantity by quantity."""
+    torch.manual_seed(0)
+    gen = ref["Generator"]("bssfp")
+    for m in gen.modules():
+        if isinstance(m, R._RefADN):
+            m.p = 0.0
+    discr = ref["Discriminator"]("bssfp")
+    gen, discr = gen.double().train(), discr.double().train()
+    g_opt, d_opt = R.make_optimizers(gen, discr)
+    x, y = R.synthetic_batch(1, 64, seed=1234)
+    x, y = x.double(), y.double()
+    store = {}
+    for step in range(2):
+        logs = R.gan_training_step(gen, discr, g_opt, d_opt, x, y)
+        for k, v in logs.items():
+            store[f"step{step}/{k}"] = np.array(v.item())
+        for k, v in _param_digest(gen).items():
+            store[f"step{step}/gen/{k}"] = v
+        for k, v in _param_digest(discr).items():
+            store[f"step{step}/discr/{k}"] = v
+    gen.eval()
+    with torch.no_grad():
+        store["final/y_hat_eval_sample"] = gen(x)[:, :, ::4, ::4, ::4].numpy().copy()
+    np.savez_compressed(os.path.join(out_dir, "gan_step_f64.npz"), **store)
+
+
 def case_dti_scalar_maps(ref_root, out_dir):
     """Runs the reference's OWN voxel loop (src/eval.py:84-116, the three nested `for` loops of
     do_calc_scalar_maps) on a small synthetic tensor field.  Only the loop statement is extracted (AST);
@@ -205,7 +234,7 @@ def main():
     os.makedirs(a.out, exist_ok=True)
     ref = load_reference_classes(a.ref)
     cases = dict(downsample=case_downsample, discriminator=case_discriminator,
-                 generator=case_generator, gan_step=case_gan_step)
+                 generator=case_generator, gan_step=case_gan_step, gan_step_f64=case_gan_step_f64)
     for name, fn in cases.items():
         if a.only and name != a.only:
             continue

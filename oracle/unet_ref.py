@@ -54,6 +54,52 @@ def _conv_nd(dims: int):
 
 
 # ----------------------------------------------------------------------------------
+# Storage emulation of the HIP path's throughput mode (NOT part of the reference): with
+# ``storage_emulation(torch.bfloat16)`` active, every tensor the HIP bf16 mode keeps in bf16 is rounded
+# through bf16 at the same point -- network inputs (pack), packed weights (f32 master weights, straight-through
+# gradient), conv / transposed-conv outputs, norm+activation outputs, and the gradients flowing back through
+# the same points (the HIP data-gradient and norm-backward kernels store bf16) -- while all arithmetic,
+# statistics and weight gradients stay f32, as in the kernels.  The f32 oracle tells how far bf16 storage moves
+# a result; the emulated oracle tells whether the KERNELS do anything beyond that (tests/test_gpu_bf16.py).
+# ----------------------------------------------------------------------------------
+_STORAGE = [None]
+
+
+class storage_emulation:
+    def __init__(self, dtype):
+        assert dtype in (None, torch.bfloat16)
+        self.dtype = dtype
+
+    def __enter__(self):
+        self.prev, _STORAGE[0] = _STORAGE[0], self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        _STORAGE[0] = self.prev
+
+
+class _RoundBoth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.dtype = dtype
+        return x.to(dtype).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype).to(g.dtype), None
+
+
+def _qa(t):
+    """activation / gradient storage point"""
+    return t if _STORAGE[0] is None else _RoundBoth.apply(t, _STORAGE[0])
+
+
+def _qw(w):
+    """packed weights: rounded value, gradient passed straight to the f32 master weight"""
+    return w if _STORAGE[0] is None else w + (w.detach().to(_STORAGE[0]).to(w.dtype) - w.detach())
+
+
+# ----------------------------------------------------------------------------------
 # src/model.py:42-65
 # ----------------------------------------------------------------------------------
 class RefDownSampleConv(nn.Module):
@@ -69,8 +115,8 @@ class RefDownSampleConv(nn.Module):
             self.bn = nn.BatchNorm3d(out_channels)
 
     def forward(self, x):
-        z = F.conv3d(x, self.conv.weight, self.conv.bias,
-                     self.conv.stride, self.conv.padding)
+        z = _qa(F.conv3d(x, _qw(self.conv.weight), self.conv.bias,
+                         self.conv.stride, self.conv.padding))
         if self.has_bn:
             z = F.batch_norm(z, self.bn.running_mean, self.bn.running_var,
                              self.bn.weight, self.bn.bias, self.training,
@@ -79,7 +125,7 @@ class RefDownSampleConv(nn.Module):
                 self.bn.num_batches_tracked += 1
         if self.has_act:
             z = F.leaky_relu(z, PATCHGAN_LRELU_SLOPE)
-        return z
+        return _qa(z) if (self.has_bn or self.has_act) else z
 
 
 # ----------------------------------------------------------------------------------
@@ -102,11 +148,11 @@ class RefDiscriminator(nn.Module):
         self.final = nn.Conv3d(512, 1, kernel_size=1)            # :83
 
     def forward(self, x, y):
-        h = torch.cat([x, y], dim=1)                             # :86
+        h = _qa(torch.cat([x, y], dim=1))                        # :86
         h = self.d1[self.modality](h)
         for blk in (self.d2, self.d3, self.d4, self.d5):
             h = blk(h)
-        return self.final(h)                                     # raw logits
+        return _qa(F.conv3d(h, _qw(self.final.weight), self.final.bias))   # raw logits
 
 
 # ----------------------------------------------------------------------------------
@@ -140,7 +186,8 @@ class _RefConvolution(nn.Module):
         self.adn = _RefADN(cout, dims, dropout)
 
     def forward(self, x):
-        return self.adn(self.conv(x))
+        c = self.conv
+        return _qa(self.adn(_qa(c._conv_forward(x, _qw(c.weight), c.bias))))
 
 
 class _RefTwoConv(nn.Module):
@@ -171,7 +218,9 @@ class _RefUpsample(nn.Module):
         self.deconv = ct(cin, cout, kernel_size=2, stride=2, bias=True)
 
     def forward(self, x):
-        return self.deconv(x)
+        d = self.deconv
+        fn = F.conv_transpose3d if isinstance(d, nn.ConvTranspose3d) else F.conv_transpose2d
+        return _qa(fn(x, _qw(d.weight), d.bias, stride=2))
 
 
 class _RefUpCat(nn.Module):
@@ -229,7 +278,8 @@ class RefBasicUNet(nn.Module):
         u3 = self.upcat_3(u4, x2)
         u2 = self.upcat_2(u3, x1)
         u1 = self.upcat_1(u2, x0)
-        return self.final_conv(u1)
+        f = self.final_conv
+        return _qa(f._conv_forward(u1, _qw(f.weight), f.bias))
 
 
 # ----------------------------------------------------------------------------------
@@ -247,7 +297,7 @@ class RefGenerator(nn.Module):
                                      "bssfp": head24, "t1w": head6, "unet": unet})
 
     def forward(self, x):
-        return self.blocks["unet"](self.blocks[self.input_modality](x))
+        return self.blocks["unet"](self.blocks[self.input_modality](_qa(x)))
 
 
 # ----------------------------------------------------------------------------------

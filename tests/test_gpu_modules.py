@@ -189,9 +189,20 @@ def test_state_dict_roundtrip_with_oracle(hip):
 
 
 def test_gan_training_step_golden(hip, golden_dir):
+    """Two full training steps at 64^3 against the goldens produced by the reference's own classes (CPU f32,
+    gan_step.npz), with float64 as the yard-stick (gan_step_f64.npz: the same two steps in f64).
+
+    Step 0 is compared directly and tightly.  From the first AdamW update on, parameters move by lr * g / |g|, so rounding
+    noise in small gradients decides signs and the f32 runs drift apart -- the CPU f32 run itself is 7e-5 (losses) to 2.5e-2
+    (single parameter digests) away from f64 after step 1.  Instead of a chosen tolerance, every quantity must satisfy
+
+        |hip_f32 - f64|  <=  3 * max(|cpu_f32 - f64|, class floor)
+
+    where the class floor is the largest CPU deviation among the step's losses / the median CPU deviation among the
+    network's parameter digests (a single quantity's CPU deviation can be tiny by chance)."""
     import unet_bssfp_amd as M
     from unet_bssfp_amd.gan import bSSFPToDWITensorModel, synthetic_batch
-    gold = _gold(golden_dir, "gan_step.npz")
+    gold, g64 = _gold(golden_dir, "gan_step.npz"), _gold(golden_dir, "gan_step_f64.npz")
     torch.manual_seed(0)
     gen = M.Generator("bssfp", dropout=0.0)
     discr = M.Discriminator("bssfp")
@@ -199,37 +210,61 @@ def test_gan_training_step_golden(hip, golden_dir):
     batch = synthetic_batch(1, 64, seed=1234, device=DEV)
     names = {"train_gen_loss_adversarial": "gen_loss_adversarial", "train_gen_loss_recon_L1": "gen_loss_recon_L1",
              "train_gen_loss_recon": "gen_loss_recon", "train_gen_loss": "gen_loss", "train_discr_loss": "discr_loss"}
-    def noisy(tag, n):            # zero-gradient biases in front of a norm: AdamW amplifies rounding noise
+    def noisy(tag, n):            # zero-gradient biases in front of a norm: AdamW turns rounding noise (also f64's) into +-lr steps
         if tag == "discr":
             return n in ("d2.conv.bias", "d3.conv.bias", "d4.conv.bias", "d5.conv.bias")
         return noisy_bias(n)
-    # Step 0 is compared tightly.  From the first AdamW update on, parameters move by lr * g/|g|:
-    # gradients that are sums with ~1000x cancellation (e.g. d1.conv.weight behind d2's BatchNorm:
-    # rel. error 1e-3 on BOTH sides vs f64) get a different sign on ~0.1 % of their elements, so
-    # step 1 is compared with a stated looser tolerance (losses 3 %, parameter abs-sums 1 %).
+    report = []
     for step in range(2):
         model.training_step(batch, step)
-        ltol = 1e-3 if step == 0 else 3e-2
+        rel = lambda v, key: abs(v - float(g64[key])) / abs(float(g64[key]))
+        cpu_dev = {gk: rel(float(gold[f"step{step}/{gk}"]), f"step{step}/{gk}") for gk in names.values()}
+        floor = max(cpu_dev.values())
         for k, gk in names.items():
-            np.testing.assert_allclose(float(model.last_logs[k]), gold[f"step{step}/{gk}"], rtol=ltol, err_msg=f"{step}/{k}")
+            got = float(model.last_logs[k])
+            if step == 0:
+                np.testing.assert_allclose(got, gold[f"step0/{gk}"], rtol=1e-3, err_msg=k)
+            dev = rel(got, f"step{step}/{gk}")
+            report.append(f"step{step} {gk}: hip {dev:.2e} cpu {cpu_dev[gk]:.2e}")
+            assert dev <= 3 * max(cpu_dev[gk], floor) + 1e-7, (step, k, dev, cpu_dev[gk], floor)
         for net, tag in ((model.gen, "gen"), (model.discr, "discr")):
-            for n, p in net.named_parameters():
-                ref = gold[f"step{step}/{tag}/{n}"]
-                if noisy(tag, n):
+            items = [(n, p) for n, p in net.named_parameters() if not noisy(tag, n)]
+            cdev = {}
+            for n, _ in items:
+                key = f"step{step}/{tag}/{n}"
+                cdev[n] = abs(gold[key][1] - g64[key][1]) / max(abs(g64[key][1]), 1e-30)
+            floor = float(np.median(list(cdev.values())))
+            worst = 0.0
+            for n, p in items:
+                key = f"step{step}/{tag}/{n}"
+                if abs(g64[key][1]) < 1e-12:
                     continue
-                d = np.array([p.detach().double().sum().item(), p.detach().double().abs().sum().item()])
-                ptol = 2e-3 if step == 0 else 1e-2
-                assert abs(d[1] - ref[1]) <= ptol * abs(ref[1]) + 5e-3, (step, tag, n, d, ref)
+                a = p.detach().double().abs().sum().item()
+                dev = abs(a - g64[key][1]) / abs(g64[key][1])
+                worst = max(worst, dev / max(cdev[n], floor))
+                assert dev <= 3 * max(cdev[n], floor) + 1e-7, (step, tag, n, dev, cdev[n], floor)
+            report.append(f"step{step} {tag}: worst hip/cpu deviation ratio {worst:.2f} (class floor {floor:.2e})")
     assert all(p.requires_grad for p in model.parameters())
     model.gen.eval()
     with torch.no_grad():
         y = model.gen(batch["bssfp"]["data"])[:, :, ::4, ::4, ::4].cpu().numpy()
-    # after two AdamW updates (see above): stated loose tolerance on O(0.3) outputs
-    assert np.abs(y - gold["final/y_hat_eval_sample"]).mean() <= 2e-2
+    ref64 = g64["final/y_hat_eval_sample"]
+    cpu_dev = np.abs(gold["final/y_hat_eval_sample"] - ref64).mean()
+    hip_dev = np.abs(y - ref64).mean()
+    report.append(f"final eval output: hip {hip_dev:.2e} cpu {cpu_dev:.2e}")
+    try:
+        with open(os.path.join(os.path.dirname(golden_dir), "..", "gpurun_out", "f64_triangulation.log"), "w") as fh:
+            fh.write("\n".join(report) + "\n")
+    except OSError:
+        pass
+    assert hip_dev <= 3 * cpu_dev, (hip_dev, cpu_dev)
 
 
 def test_gan_step_matches_oracle_n2_s64_with_torch_adamw(hip):
-    """Same step driven with torch.optim.AdamW on both sides isolates the kernels from the optimiser."""
+    """Same step driven with torch.optim.AdamW on both sides isolates the kernels from the optimiser.  Step 0 tightly;
+    step 1 (after the sign-like first AdamW update) triangulated against an f64 run of the oracle made here:
+    |hip - f64| <= 3 * max over the losses of |cpu_f32 - f64|."""
+    import copy
     import unet_bssfp_amd as M
     from unet_bssfp_amd.gan import bSSFPToDWITensorModel, synthetic_batch
     torch.manual_seed(3)
@@ -237,18 +272,25 @@ def test_gan_step_matches_oracle_n2_s64_with_torch_adamw(hip):
     rgen, rdiscr = R.RefGenerator("bssfp", dropout=0.0).train(), R.RefDiscriminator("bssfp").train()
     rgen.load_state_dict(gen.state_dict())
     rdiscr.load_state_dict(discr.state_dict())
+    dgen, ddiscr = copy.deepcopy(rgen).double(), copy.deepcopy(rdiscr).double()
     model = bSSFPToDWITensorModel("bssfp", gen=gen.to(DEV), discr=discr.to(DEV), optimizer_class=torch.optim.AdamW).train()
     # 64^3 so that the last PatchGAN BatchNorm sees 16 values per channel (2 would be chaotic)
     batch = synthetic_batch(2, 64, seed=77, device=DEV)
     x, y = R.synthetic_batch(2, 64, seed=77)
     g_opt, d_opt = R.make_optimizers(rgen, rdiscr)
+    g_opt64, d_opt64 = R.make_optimizers(dgen, ddiscr)
+    keys = ("gen_loss_adversarial", "gen_loss_recon_L1", "gen_loss_recon", "gen_loss", "discr_loss")
     for step in range(2):
         model.training_step(batch, step)
         ref = R.gan_training_step(rgen, rdiscr, g_opt, d_opt, x, y)
-        for k in ("gen_loss_adversarial", "gen_loss_recon_L1", "gen_loss_recon", "gen_loss", "discr_loss"):
-            # step 1 follows an AdamW update (sign-like at t=1): see test_gan_training_step_golden
-            np.testing.assert_allclose(float(model.last_logs["train_" + k]), float(ref[k]), rtol=1e-3 if step == 0 else 3e-2,
-                                       err_msg=f"{step}/{k}")
+        r64 = R.gan_training_step(dgen, ddiscr, g_opt64, d_opt64, x.double(), y.double())
+        cpu_dev = max(abs(float(ref[k]) - float(r64[k])) / abs(float(r64[k])) for k in keys)
+        for k in keys:
+            got = float(model.last_logs["train_" + k])
+            if step == 0:
+                np.testing.assert_allclose(got, float(ref[k]), rtol=1e-3, err_msg=f"{step}/{k}")
+            dev = abs(got - float(r64[k])) / abs(float(r64[k]))
+            assert dev <= 3 * cpu_dev + 1e-7, (step, k, dev, cpu_dev)
     # BatchNorm buffers advanced identically: head BN twice per step, PatchGAN BN three times per step
     assert int(model.gen.blocks["bssfp"].bn.num_batches_tracked) == int(rgen.blocks["bssfp"].bn.num_batches_tracked) == 4
     assert int(model.discr.d2.bn.num_batches_tracked) == int(rdiscr.d2.bn.num_batches_tracked) == 6
@@ -274,23 +316,6 @@ def test_fused_adamw_matches_torch(hip):
         ob.step()
     for pa, pb in zip(a, b):
         torch.testing.assert_close(pa.detach().cpu(), pb.detach(), rtol=1e-5, atol=1e-6)
-
-
-def test_bf16_generator_tracks_oracle(hip):
-    """Throughput mode (bf16 storage, f32 accumulate/statistics): stated tolerance, not the 1e-4 gate."""
-    import unet_bssfp_amd as M
-    torch.manual_seed(8)
-    g = M.Generator("bssfp", dropout=0.0)
-    ref = R.RefGenerator("bssfp", dropout=0.0).train()
-    ref.load_state_dict(g.state_dict())
-    x, _ = R.synthetic_batch(1, 32, seed=5)
-    g = M.set_compute_dtype(g.to(DEV).train(), torch.bfloat16)
-    with torch.no_grad():
-        y = g(x.to(DEV)).cpu()
-        y_ref = ref(x)
-    err = (y - y_ref).abs().mean().item()
-    scale = y_ref.abs().mean().item()
-    assert err <= 0.05 * max(scale, 0.1), (err, scale)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -1,8 +1,14 @@
 """GPU parity of every HIP kernel (through the C ABI) against plain PyTorch CPU f32 ops.
 
-Tolerances (f32 path): the f32 MFMA is an exact fmaf chain, so differences come only from the
-summation order: rtol 2e-4 / atol 2e-5 on O(1) data.  bf16 path (bf16 storage, f32 accumulate):
-rtol 3e-2 / atol 3e-2.
+Tolerances, derived:
+* f32 path: the f32 MFMA is an exact fmaf chain, so differences come only from the summation order:
+  rtol 2e-4 / atol 2e-5 on O(1) data.
+* bf16 path: the test feeds bf16-representable inputs and weights, products of two bf16 values are exact in f32 and
+  the kernels accumulate in f32, so the ONLY legitimate error of a bf16 OUTPUT is its final rounding (half an ulp =
+  2^-9 = 2e-3 relative): `close()` allows rtol 1e-2 plus atol 2e-3 * sigma(reference) for values near zero.
+* weight / bias gradients are f32 OUTPUTS in both modes: sums over all output positions whose only error is the f32
+  summation order, bounded relative to the largest element: |err| <= 2e-3 * max|ref| (measured ~1e-5 .. 1e-4); an
+  all-zero or mis-scaled gradient fails by a factor of 500.
 """
 import math
 import zlib
@@ -14,7 +20,23 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
-TOL = {torch.float32: dict(rtol=2e-4, atol=2e-5), torch.bfloat16: dict(rtol=3e-2, atol=3e-2)}
+TOL = {torch.float32: dict(rtol=2e-4, atol=2e-5)}
+
+
+def close(got, ref, dtype, what=""):
+    """Output stored in `dtype`: f32 -> summation-order noise only; bf16 -> final rounding (see the module docstring)."""
+    if dtype == torch.float32:
+        torch.testing.assert_close(got, ref, **TOL[dtype], msg=lambda m: f"{what}: {m}")
+    else:
+        sigma = float(ref.float().std()) if ref.numel() > 1 else float(ref.abs().max())
+        torch.testing.assert_close(got, ref, rtol=1e-2, atol=2e-3 * max(sigma, 1e-30), msg=lambda m: f"{what}: {m}")
+
+
+def close_f32_sum(got, ref, what=""):
+    """f32 reductions over many positions (weight / bias / affine gradients): error relative to the largest element."""
+    scale = float(ref.abs().max())
+    err = float((got - ref).abs().max())
+    assert err <= 2e-3 * scale + 1e-12, f"{what}: max |err| {err:.3e} > 2e-3 * max|ref| ({scale:.3e})"
 
 
 def _ops():
@@ -126,29 +148,27 @@ def test_conv_fwd_bwd(hip, case, dtype):
         _ops().CONV_PROBE = None
     if name.startswith("k3_ru") and dtype == torch.bfloat16:
         assert plans and plans[0] in (31941, 31942), plans      # conv_ru_kernel<1> / <2>
-    tol = TOL[dtype]
-    torch.testing.assert_close(from_act(z, cout), z_ref.detach(), **tol)
+    close(from_act(z, cout), z_ref.detach(), dtype, "z")
     cp = z.shape[4]
     if cp > cout:                                        # pad channels must hold zeros
         assert float(z[..., cout:].abs().max()) == 0.0
     # fused statistics of (z - bias): per-tile partial sums
     s = part.sum(0).cpu()                                # [2][coutp]
     zc = (z_ref.detach() - b_cpu.detach().view(1, -1, 1, 1, 1))
-    torch.testing.assert_close(s[0, :cout], zc.sum((0, 2, 3, 4)), rtol=2e-3, atol=2e-2 if dtype == torch.float32 else 0.5)
-    torch.testing.assert_close(s[1, :cout], (zc * zc).sum((0, 2, 3, 4)), rtol=2e-3 if dtype == torch.float32 else 2e-2, atol=1e-2)
+    # (computed from the f32 accumulators, before the output is rounded: f32 summation-order noise only).  The signed sum
+    # cancels, so it is bounded on the scale of sum |z - b| <= sqrt(N * sum (z - b)^2)
+    n_pos = zc.numel() / cout
+    e0 = (s[0, :cout] - zc.sum((0, 2, 3, 4))).abs()
+    assert bool((e0 <= 2e-3 * (n_pos * (zc * zc).sum((0, 2, 3, 4))).sqrt() + 1e-6).all()), e0.max()
+    close_f32_sum(s[1, :cout], (zc * zc).sum((0, 2, 3, 4)), "sum (z-b)^2")
     # backward
     z.backward(to_act(gz, dtype))
     off = 0
-    btol = tol if dtype == torch.float32 else dict(rtol=5e-2, atol=1e-1)
     for a, c in zip(acts, cins):
-        torch.testing.assert_close(from_act(a.grad, c), xcat.grad[:, off:off + c], **btol)
+        close(from_act(a.grad, c), xcat.grad[:, off:off + c], dtype, "dx")
         off += c
-    wscale = float(w_cpu.grad.abs().max())
-    # sums over all output positions of zero-mean values: rounding noise of differently ordered f32 accumulations
-    # grows with sqrt(positions)
-    grow = max(1.0, (z_ref.numel() / cout) ** 0.5 / 30.0)
-    torch.testing.assert_close(layer.weight.grad.cpu(), w_cpu.grad, rtol=tol["rtol"] * 5, atol=tol["atol"] * 5 * max(1.0, wscale) * grow)
-    torch.testing.assert_close(layer.bias.grad.cpu(), b_cpu.grad, rtol=tol["rtol"] * 5, atol=tol["atol"] * 50 * grow)
+    close_f32_sum(layer.weight.grad.cpu(), w_cpu.grad, "dw")
+    close_f32_sum(layer.bias.grad.cpu(), b_cpu.grad, "db")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -172,16 +192,11 @@ def test_deconv_fwd_bwd(hip, dtype, cin, cout, sp):
     layer = layer.to(DEV)
     a = to_act(x, dtype).requires_grad_(True)
     z = layer.forward_act(a)
-    tol = TOL[dtype]
-    torch.testing.assert_close(from_act(z, cout), z_ref.detach(), **tol)
+    close(from_act(z, cout), z_ref.detach(), dtype, "z")
     z.backward(to_act(gz, dtype))
-    btol = tol if dtype == torch.float32 else dict(rtol=5e-2, atol=1e-1)
-    torch.testing.assert_close(from_act(a.grad, cin), x_cpu.grad, **btol)
-    # sums over all output positions of zero-mean values: the rounding noise of the (differently ordered) f32
-    # accumulations grows with sqrt(positions)
-    grow = max(1.0, (z_ref.numel() / cout) ** 0.5 / 30.0)
-    torch.testing.assert_close(layer.weight.grad.cpu(), w_cpu.grad, rtol=tol["rtol"] * 5, atol=tol["atol"] * 50 * grow)
-    torch.testing.assert_close(layer.bias.grad.cpu(), b_cpu.grad, rtol=tol["rtol"] * 5, atol=tol["atol"] * 50 * grow)
+    close(from_act(a.grad, cin), x_cpu.grad, dtype, "dx")
+    close_f32_sum(layer.weight.grad.cpu(), w_cpu.grad, "dw")
+    close_f32_sum(layer.bias.grad.cpu(), b_cpu.grad, "db")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -217,15 +232,15 @@ def test_normact_fwd_bwd(hip, dtype, kind, n, c, sp):
     else:
         a = Fn.NormActFn.apply(zd, None, gd, bd, None, cfg, True, rmd if kind == "batch" else None,
                                rvd if kind == "batch" else None)
-    tol = TOL[dtype]
-    torch.testing.assert_close(from_act(a, c), a_ref.detach(), **tol)
+    close(from_act(a, c), a_ref.detach(), dtype, "a")
     a.backward(to_act(ga, dtype))
-    btol = dict(rtol=1e-3, atol=1e-5) if dtype == torch.float32 else dict(rtol=5e-2, atol=5e-2)
-    torch.testing.assert_close(from_act(zd.grad, c), z_cpu.grad, **btol)
+    if dtype == torch.float32:
+        torch.testing.assert_close(from_act(zd.grad, c), z_cpu.grad, rtol=1e-3, atol=1e-5)
+    else:
+        close(from_act(zd.grad, c), z_cpu.grad, dtype, "dz")
     if kind != "none":
-        nel = z.numel() / c
-        torch.testing.assert_close(gd.grad.cpu(), g_cpu.grad, rtol=1e-3 if dtype == torch.float32 else 5e-2, atol=1e-5 * nel if dtype == torch.float32 else 1e-2 * math.sqrt(nel))
-        torch.testing.assert_close(bd.grad.cpu(), b_cpu.grad, rtol=1e-3 if dtype == torch.float32 else 5e-2, atol=1e-5 * nel if dtype == torch.float32 else 1e-2 * math.sqrt(nel))
+        close_f32_sum(gd.grad.cpu(), g_cpu.grad, "dgamma")     # f32 outputs in both modes
+        close_f32_sum(bd.grad.cpu(), b_cpu.grad, "dbeta")
     if kind == "batch":
         torch.testing.assert_close(rmd.cpu(), rm, rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(rvd.cpu(), rv, rtol=1e-4, atol=1e-6)
@@ -247,9 +262,9 @@ def test_batchnorm_eval_mode(hip, dtype):
     zd = to_act(z, dtype).requires_grad_(True)
     rmd, rvd = rm.to(DEV), rv.to(DEV)
     a = Fn.NormActFn.apply(zd, None, gamma.to(DEV), beta.to(DEV), None, cfg, False, rmd, rvd)
-    torch.testing.assert_close(from_act(a, c), a_ref.detach(), **TOL[dtype])
+    close(from_act(a, c), a_ref.detach(), dtype, "a")
     a.backward(to_act(ga, dtype))
-    torch.testing.assert_close(from_act(zd.grad, c), z_cpu.grad, **(TOL[dtype] if dtype == torch.float32 else dict(rtol=5e-2, atol=5e-2)))
+    close(from_act(zd.grad, c), z_cpu.grad, dtype, "dz")
     assert torch.equal(rmd.cpu(), rm) and torch.equal(rvd.cpu(), rv)     # eval: buffers untouched
 
 
@@ -277,10 +292,10 @@ def test_dropout_statistics_and_backward_mask(hip, dtype):
     assert abs(dropped - p) < 0.004                       # ~131k elements: sigma ~ 6e-4
     ref = F.leaky_relu(F.instance_norm(z, eps=1e-5), 0.1) / (1 - p)
     keep = av != 0
-    torch.testing.assert_close(av[keep], ref[keep], **TOL[dtype])
+    close(av[keep], ref[keep], dtype, "kept")
     # eval mode: no dropout
     a_eval = Fn.NormActFn.apply(zd, None, ones, zeros, None, cfg, False, None, None)
-    torch.testing.assert_close(from_act(a_eval, c), ref * (1 - p), **TOL[dtype])
+    close(from_act(a_eval, c), ref * (1 - p), dtype, "eval")
     # backward uses the same mask: dz is exactly 0-contribution where dropped => check via linearity
     a.backward(to_act(torch.ones(1, c, 16, 16, 16), dtype))
     assert torch.isfinite(zd.grad.float()).all()
@@ -375,17 +390,15 @@ def test_k4s2_conv_as_dense_k2_on_s2d(hip, dtype, n, cin, cout, sp):
     cp = _ops().round_up(cin, 16)
     s = to_s2d(x, dtype, cp).requires_grad_(True)
     z, part = Fn.ConvFn.apply(s, None, layer.weight, layer.bias, layer.spec, True, False, cp)
-    tol = TOL[dtype]
-    torch.testing.assert_close(from_act(z, cout), z_ref.detach(), **tol)
+    close(from_act(z, cout), z_ref.detach(), dtype, "z")
     zc = z_ref.detach() - b_cpu.detach().view(1, -1, 1, 1, 1)
-    torch.testing.assert_close(part.sum(0).cpu()[0, :cout], zc.sum((0, 2, 3, 4)), rtol=2e-3, atol=2e-2 if dtype == torch.float32 else 0.5)
+    e0 = (part.sum(0).cpu()[0, :cout] - zc.sum((0, 2, 3, 4))).abs()
+    assert bool((e0 <= 2e-3 * ((zc.numel() / cout) * (zc * zc).sum((0, 2, 3, 4))).sqrt() + 1e-6).all()), e0.max()
     z.backward(to_act(gz, dtype))
     dx = _ops().unpack_ncdhw_s2d(s.grad, cin, sp, cp, 0).cpu()
-    btol = tol if dtype == torch.float32 else dict(rtol=5e-2, atol=1e-1)
-    torch.testing.assert_close(dx, x_cpu.grad, **btol)
-    wscale = float(w_cpu.grad.abs().max())
-    torch.testing.assert_close(layer.weight.grad.cpu(), w_cpu.grad, rtol=tol["rtol"] * 5, atol=tol["atol"] * 5 * max(1.0, wscale))
-    torch.testing.assert_close(layer.bias.grad.cpu(), b_cpu.grad, rtol=tol["rtol"] * 5, atol=tol["atol"] * 50)
+    close(dx, x_cpu.grad, dtype, "dx")
+    close_f32_sum(layer.weight.grad.cpu(), w_cpu.grad, "dw")
+    close_f32_sum(layer.bias.grad.cpu(), b_cpu.grad, "db")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -474,14 +487,14 @@ def test_skip_pool_sums_both_gradients_in_the_pool_backward(hip, dtype):
     wide = torch.zeros(2, 8, 12, 16, 48, dtype=dtype, device=DEV)
     wide[..., :32] = to_act(gs, dtype)
     torch.autograd.backward([skip, pooled], [wide[..., :32], to_act(gp, dtype)])
-    torch.testing.assert_close(from_act(a.grad, 32), xr.grad, **TOL[dtype])
+    close(from_act(a.grad, 32), xr.grad, dtype, "skip + pool")
     # only one of the two uses reaches the loss
     a2 = to_act(x, dtype).requires_grad_(True)
     s2, p2 = Fn.SkipPoolFn.apply(a2)
     p2.backward(to_act(gp, dtype))
     x2 = x.clone().requires_grad_(True)
     (F.max_pool3d(x2, 2) * gp).sum().backward()
-    torch.testing.assert_close(from_act(a2.grad, 32), x2.grad, **TOL[dtype])
+    close(from_act(a2.grad, 32), x2.grad, dtype, "pool only")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -150,3 +150,26 @@ def test_gan_step_matches_reference(golden_dir):
     # all parameters require grad again after the step (toggle/untoggle restored)
     assert all(p.requires_grad for p in gen.parameters())
     assert all(p.requires_grad for p in discr.parameters())
+
+
+def test_storage_emulation_rounds_where_the_bf16_mode_stores():
+    """oracle.storage_emulation (test infrastructure for the bf16 GPU tests): off = bit-identical to the plain oracle;
+    on = outputs and data gradients are bf16-representable, weight gradients stay full-precision f32 sums and reach the
+    f32 master weights (straight-through)."""
+    import torch
+    from oracle import unet_ref as R
+    torch.manual_seed(0)
+    m = R.RefDownSampleConv(16, 32).train()
+    x = torch.rand(2, 16, 8, 8, 8)
+    y0 = m(x)
+    with R.storage_emulation(None):
+        assert torch.equal(m(x), y0)
+    xr = x.clone().requires_grad_(True)
+    with R.storage_emulation(torch.bfloat16):
+        y1 = m(xr)
+        (y1 * torch.rand_like(y1)).sum().backward()
+    assert torch.equal(y1, y1.to(torch.bfloat16).float()) and not torch.equal(y1, y0)
+    assert (y1 - y0).abs().max() <= 0.05 * y0.abs().max()
+    w = m.conv.weight
+    assert w.grad is not None and not torch.equal(w.grad, w.grad.to(torch.bfloat16).float())
+    assert xr.grad is not None          # (x itself is rounded by the caller: Generator / Discriminator entry)
