@@ -6,24 +6,35 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one full ``training_step`` (src/model.py:259-281: generator phase + discriminator
-phase, both AdamW updates) on one 1x24x128^3 volume per GPU, inputs resident in HBM.  Rank 0
-prints ONE JSON line (metric/unit from BASELINE.json) carrying
+phase, both AdamW updates) on one 1x24x128^3 volume per GPU, inputs resident in HBM.  W untimed
+warm-up steps, then (untimed, reported as ``settle_steps``) further steps until the GPU has been
+busy for ``--settle-s`` seconds so that the clock the chip holds under sustained MFMA load is reached,
+then EXACTLY K timed steps between barrier + synchronize pairs; MAX over ranks.  Rank 0 prints ONE JSON
+line (metric/unit from BASELINE.json) carrying
 
-* ``roofline``     -- the dominant kernel family (3x3x3 implicit-GEMM conv at full resolution with 32
-  output channels: ``conv_ru_kernel<1>`` in bf16, ``conv_halo_kernel<float,3,2,4,32,1>`` in f32):
-  algorithmic FLOPs of all its launches / their summed duration, measured live with HIP events on
-  the launch stream; peak = dense MFMA peak of the dtype (MI355X_MICROARCH.md: bf16 ~2.5 PF,
-  f32-matrix 157.3 TF); ``traffic`` = HBM-side bytes per launch from rocprofv3 PMC passes of the same
-  step (profiles/r01_pmc_step_traffic.txt).
+* ``roofline``     -- the dominant kernel family = the convolution plan with the largest summed duration
+  (measured, not assumed): algorithmic FLOPs of all its launches / their summed duration, HIP events on
+  the launch stream around every launch; peak = dense MFMA peak of the dtype (MI355X_MICROARCH.md:
+  bf16 ~2.5 PF, f32-matrix 157.3 TF, fp8 ~5 PF).  ``traffic`` = HBM-side bytes per launch from rocprofv3 PMC
+  passes (separate --pmc runs, 2 x FETCH_SIZE + WRITE_SIZE: gfx950 counts 16-B/lane read streams at half
+  their bytes) recorded in profiles/*_traffic.json together with a hash of the kernel sources; it is
+  reported only when that hash matches the sources this run was built from, else null.
+* ``roofline_hbm`` -- the fused norm + dropout + LeakyReLU kernels (forward / backward): algorithmic bytes
+  per SURVEY 8(d) (forward 2*C*V*b, backward 3*C*V*b) / event time, against 8 TB/s.
 * ``cpu_baseline`` -- the CPU oracle (oracle/unet_ref.py, kind "port") timed on the host cores on
-  a bounded sample (one step at the same 128^3 size), rank 0 at N=1 only.  A reported baseline,
-  not the target.
+  a bounded sample (3 steps at the same 128^3 size after a warm-up), rank 0 at N=1 only.  A reported
+  baseline, not the target.
+
+``--fresh-batch`` feeds a NEW host batch to every step (pinned double buffer -> staging buffer on a side
+stream under the previous step -> device-to-device copy into the graph's static inputs).
 
 The Perceptual loss term (src/model.py:127-129) needs remotely fetched weights and is absent.
 """
 from __future__ import annotations
 
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -36,59 +47,78 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
-# dominant kernel family = full-resolution 3x3x3 implicit GEMM with 32 output channels
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "fp8": 5000.0}
+HBM_PEAK_GBS = 8000.0
 # plan id = 10000*ks + 1000*halo + 100*tile_shape + 10*voxel_subtiles_per_wave + cout_subtiles_per_wave
-DOMINANT_PLAN = {"bf16": (31941, "conv_ru_kernel<1>"), "f32": (31021, "conv_halo_kernel<float,3,2,4,32,1>")}
-# HBM-side bytes per launch of the dominant kernel in THIS workload (1x24x128^3 GAN step), from rocprofv3 PMC passes
-# of the same step (`tools/pmc_step.sh`, profiles/r01_pmc_step_traffic.txt): 2 x FETCH_SIZE (gfx950 counts the 128-B
-# requests of 16-B/lane streams at 64 B) + WRITE_SIZE, averaged over the kernel's launches.  bench.py cannot collect
-# counters itself; other sizes / dtypes report null.
-PROFILED_TRAFFIC = {("bf16", 128, "gan_step"): 2 * 268627.3e3 + 153600.0e3}
+PLAN_NAMES = {31941: "conv_ru_kernel<1>", 31942: "conv_ru_kernel<2>", 31021: "conv_halo_kernel<float,3,2,4,32,1>",
+              31022: "conv_halo_kernel<float,3,2,4,32,2>"}
+KERNEL_SOURCES = ("conv_kernels.h", "conv_common.h", "conv_api.hip", "common.h")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--settle-s", type=float, default=2.0, help="untimed extra steps until the GPU has run this long")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--batch", type=int, default=1, help="volumes per GPU per step")
-    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--dtype", choices=["bf16", "f32", "fp8"], default="bf16")
     ap.add_argument("--workload", choices=["gan_step", "gen_only"], default="gan_step")
     ap.add_argument("--dropout", type=float, default=0.05)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of as hipGraph replays")
+    ap.add_argument("--fresh-batch", action="store_true", help="a new host batch every step (H2D hidden on a side stream)")
+    ap.add_argument("--lib", default=None, help="developer A/B: another build of the C ABI (tools/diaglib.py); reported")
     return ap.parse_args()
 
 
-class KernelProbe:
-    """Brackets every launch of one conv kernel family with HIP events on the launch stream."""
+class Probe:
+    """Brackets launches with HIP events on the launch stream (torch's current stream = the stream the C ABI
+    launches on).  conv launches are grouped by plan id, norm launches by direction."""
 
-    def __init__(self, plan_id):
-        self.plan_id = plan_id
-        self.events = []
-        self.flops = 0.0
+    def __init__(self):
         self.enabled = False
+        self.conv = {}          # plan id -> [events, flops]
+        self.norm = {}          # "fwd" / "bwd" -> [events, algorithmic bytes]
 
-    def __call__(self, plan_id, d, real):
-        if not self.enabled or plan_id != self.plan_id:
-            return None
-        # algorithmic FLOPs of this launch: 2 * Cin * Cout * taps * positions on the REAL channel counts
-        cin, cout = real if real is not None else (d.c0 + d.c1, d.cstore)
-        self.flops += 2.0 * cin * cout * (d.ks ** 3) * d.n * d.do_ * d.ho * d.wo
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
+    def _bracket(self, store, key, work):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ent = store.setdefault(key, [[], 0.0])
+        ent[0].append((e0, e1))
+        ent[1] += work
         e0.record()
-        self.events.append((e0, e1))
         return e1.record
 
-    def summary(self):
-        if not self.events:
+    def conv_probe(self, plan_id, d, real):
+        if not self.enabled:
             return None
-        ms = sum(a.elapsed_time(b) for a, b in self.events)
-        return dict(launches=len(self.events), total_ms=ms, avg_ms=ms / len(self.events), flops=self.flops)
+        cin, cout = real if real is not None else (d.c0 + d.c1, d.cstore)
+        return self._bracket(self.conv, plan_id, 2.0 * cin * cout * (d.ks ** 3) * d.n * d.do_ * d.ho * d.wo)
+
+    def norm_probe(self, kind, c_real, rows, elem_bytes):
+        if not self.enabled:
+            return None
+        passes = 2 if kind == "fwd" else 3           # SURVEY 8(d): fwd read z + write a; bwd read dy, read z, write dz
+        return self._bracket(self.norm, kind, float(passes) * c_real * rows * elem_bytes)
+
+    @staticmethod
+    def _sum(ent):
+        ms = sum(a.elapsed_time(b) for a, b in ent[0])
+        return dict(launches=len(ent[0]), total_ms=ms, avg_ms=ms / max(1, len(ent[0])), work=ent[1])
+
+    def dominant_conv(self):
+        best = None
+        for pid, ent in self.conv.items():
+            s = self._sum(ent)
+            if best is None or s["total_ms"] > best[1]["total_ms"]:
+                best = (pid, s)
+        return best
+
+    def norm_summary(self):
+        return {k: self._sum(v) for k, v in self.norm.items()}
 
 
 def host_cores() -> int:
@@ -108,29 +138,102 @@ def host_cores() -> int:
     return max(1, min(n, int(os.environ.get("MI355_HOST_CORES", "16"))))
 
 
-def cpu_baseline(size, workload):
+def cpu_baseline(size, workload, nsteps):
     from oracle import unet_ref as R
     torch.set_num_threads(host_cores())
     torch.manual_seed(0)
     gen = R.RefGenerator("bssfp", dropout=0.05).train()
     discr = R.RefDiscriminator("bssfp").train()
     g_opt, d_opt = R.make_optimizers(gen, discr)
-    xs, ys = R.synthetic_batch(1, 32, seed=1)
     x2, y2 = R.synthetic_batch(2, 32, seed=1)
     R.gan_training_step(gen, discr, g_opt, d_opt, x2, y2)       # warm-up (thread pools, allocators) at 32^3
     x, y = R.synthetic_batch(1, size, seed=1234)
-    t0 = time.perf_counter()
-    if workload == "gan_step":
-        R.gan_training_step(gen, discr, g_opt, d_opt, x, y)
-    else:
-        loss = torch.nn.functional.l1_loss(gen(x), y)
-        loss.backward()
-        g_opt.step()
-        g_opt.zero_grad()
-    dt = time.perf_counter() - t0
-    return dict(value=1.0 / dt, unit="volumes/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"1 {workload} step on one 1x24x{size}^3 volume after a 32^3 warm-up step ({dt:.1f} s), "
-                       "torch CPU f32, L1 + adversarial loss (no Perceptual term)")
+    times = []
+    for _ in range(max(1, nsteps)):
+        t0 = time.perf_counter()
+        if workload == "gan_step":
+            R.gan_training_step(gen, discr, g_opt, d_opt, x, y)
+        else:
+            loss = torch.nn.functional.l1_loss(gen(x), y)
+            loss.backward()
+            g_opt.step()
+            g_opt.zero_grad()
+        times.append(time.perf_counter() - t0)
+    mean = sum(times) / len(times)
+    return dict(value=1.0 / mean, unit="volumes/s", cores=torch.get_num_threads(), kind="port",
+                n_steps=len(times), s_per_step_min=min(times), s_per_step_max=max(times),
+                sample=f"{len(times)} {workload} steps on one 1x24x{size}^3 volume after a 32^3 warm-up step "
+                       f"({mean:.1f} s per step, min {min(times):.1f} / max {max(times):.1f}), torch CPU f32, "
+                       "L1 + adversarial loss (no Perceptual term)")
+
+
+def kernel_source_hash() -> str:
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "unet_bssfp_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def profiled_traffic(kernel, dtype, size, workload, batch):
+    """HBM bytes per launch of `kernel` from the newest profiles/*_traffic.json entry whose recorded kernel-source hash
+    equals the sources of this build; (None, reason) otherwise."""
+    src = kernel_source_hash()
+    stale = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        for e in rec.get("entries", []):
+            if (e.get("kernel"), e.get("dtype"), e.get("size"), e.get("workload"), e.get("batch", 1)) != (kernel, dtype, size, workload, batch):
+                continue
+            if rec.get("kernel_source_sha16") == src:
+                return e["hbm_bytes_per_launch"], dict(file=os.path.relpath(path, ROOT), git_head=rec.get("git_head"),
+                                                       kernel_source_sha16=src, method=rec.get("method"))
+            stale = os.path.relpath(path, ROOT)
+    return None, dict(reason=("kernel sources changed since " + stale) if stale else "no PMC record for this kernel / workload",
+                      kernel_source_sha16=src)
+
+
+class FreshBatches:
+    """A new host batch per step: pinned host double buffer -> device staging buffer on a side stream (overlaps the
+    running step) -> device-to-device copy into the graph's static input tensors at the step boundary."""
+
+    def __init__(self, gstep, nbuf=2):
+        self.gstep = gstep
+        self.stream = torch.cuda.Stream()
+        self.keys = [(k, v["data"]) for k, v in gstep.batch.items() if isinstance(v, dict) and "data" in v]
+        uniq, seen = [], set()
+        for k, t in self.keys:                                   # 'dwi-tensor' and 'dwi-tensor_orig' share one tensor
+            if t.data_ptr() not in seen:
+                seen.add(t.data_ptr())
+                uniq.append((k, t))
+        self.keys = uniq
+        g = torch.Generator().manual_seed(4321)
+        self.host = [[torch.rand(t.shape, generator=g).pin_memory() for _, t in self.keys] for _ in range(nbuf)]
+        self.staging = [torch.empty_like(t) for _, t in self.keys]
+        self.ready = torch.cuda.Event()
+        self.consumed = torch.cuda.Event()
+        self.consumed.record()
+        self.i = 0
+        self.prefetch()
+
+    def prefetch(self):
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(self.consumed)                # the staging buffer has been copied out
+            for s, h in zip(self.staging, self.host[self.i % len(self.host)]):
+                s.copy_(h, non_blocking=True)
+            self.ready.record(self.stream)
+        self.i += 1
+
+    def swap_in(self):
+        cur = torch.cuda.current_stream()
+        cur.wait_event(self.ready)
+        for (_, t), s in zip(self.keys, self.staging):
+            t.copy_(s, non_blocking=True)
+        self.consumed.record(cur)
+        self.prefetch()                                          # next batch crosses PCIe under this step
 
 
 def main():
@@ -147,12 +250,16 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+    nondefault = {k: v for k, v in os.environ.items() if k.startswith("MI355_") and k != "MI355_HOST_CORES"}
+    if a.lib:
+        from tools import diaglib
+        nondefault["lib"] = diaglib.use(a.lib)
 
     import unet_bssfp_amd as M
     from unet_bssfp_amd import ddp, ops
     from unet_bssfp_amd.gan import bSSFPToDWITensorModel, synthetic_batch
 
-    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dtype = M.compute_dtype_from_name(a.dtype)
     torch.manual_seed(0)                                   # identical init on every rank
     gen = M.Generator("bssfp", dropout=a.dropout)
     discr = M.Discriminator("bssfp")
@@ -178,15 +285,22 @@ def main():
             gen_opt.step()
             gen_opt.zero_grad()
 
-    probe = KernelProbe(DOMINANT_PLAN[a.dtype][0])
+    probe = Probe()
     mode = "eager"
+    fresh = None
     if use_graph:
         from unet_bssfp_amd.gan import GraphedTrainingStep
         if world > 1:
             ddp.broadcast_module_state(model.gen, 0)
             ddp.broadcast_module_state(model.discr, 0)
-        gstep = GraphedTrainingStep(model, batch, warmup=max(2, a.warmup))    # eager warm-up + capture
-        step = lambda i: gstep()
+        gstep = GraphedTrainingStep(model, batch, warmup=2)    # 2 eager steps (allocations, caches, optimiser state) + capture
+        if a.fresh_batch:
+            fresh = FreshBatches(gstep)
+
+        def step(i):
+            if fresh is not None:
+                fresh.swap_in()
+            gstep()
         mode = "hipgraph"
     else:
         if world > 1:
@@ -196,21 +310,37 @@ def main():
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
+    # settle: keep the chip under the same load until it has been busy for --settle-s (clock / thermal steady state)
+    settle_steps = 0
+    t_s = time.perf_counter()
+    while time.perf_counter() - t_s < a.settle_s:
+        for _ in range(5):
+            step(a.warmup + settle_steps)
+            settle_steps += 1
+        torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     if mode == "eager" and not a.no_probe:
-        ops.CONV_PROBE = probe
+        ops.CONV_PROBE, ops.NORM_PROBE = probe.conv_probe, probe.norm_probe
         probe.enabled = True
+    half = a.steps // 2
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     t0 = time.perf_counter()
+    ev[0].record()
     for i in range(a.steps):
-        step(a.warmup + i)
+        if i == half:
+            ev[1].record()
+        step(a.warmup + settle_steps + i)
+    ev[2].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     probe.enabled = False
+    first_ms = ev[0].elapsed_time(ev[1]) / max(1, half)
+    last_ms = ev[1].elapsed_time(ev[2]) / max(1, a.steps - half)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -219,13 +349,14 @@ def main():
     if mode == "hipgraph" and not a.no_probe and rank == 0 and world == 1:
         # inside a graph replay single kernels cannot be bracketed with events: time the same launches
         # (same tensors, same kernels) in an eager replica pass right after the timed region
-        ops.CONV_PROBE = probe
+        ops.CONV_PROBE, ops.NORM_PROBE = probe.conv_probe, probe.norm_probe
         probe.enabled = True
         for i in range(2):
             gstep._eager_step()
         torch.cuda.synchronize()
         probe.enabled = False
         probe_mode = "eager replica pass (2 steps) right after the hipGraph-timed region"
+    ops.CONV_PROBE = ops.NORM_PROBE = None
 
     if rank == 0:
         vols = a.steps * a.batch * world
@@ -240,20 +371,36 @@ def main():
                        if a.workload == "gan_step" else f"{a.workload}: generator fwd+bwd, L1 loss, AdamW",
                        "volume": f"{a.batch}x24x{a.size}^3 -> 6ch per GPU", "global_batch": a.batch * world,
                        "dropout": a.dropout, "perceptual_term": "absent (needs remote weights)",
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}",
+                       "input_feed": "new host batch every step, H2D on a side stream" if fresh is not None else "one batch resident in HBM"},
             "step_tflops": flop_per_vol * vols / dt / 1e12,
             "launch_mode": mode,
+            "timed_region_s": dt, "settle_steps": settle_steps,
+            "ms_per_step_first_half": first_ms, "ms_per_step_last_half": last_ms,
+            "nondefault": nondefault or None,
         }
-        s = probe.summary()
-        if s:
-            ach = s["flops"] / (s["total_ms"] * 1e-3) / 1e12
+        dom = probe.dominant_conv()
+        if dom:
+            pid, s = dom
+            name = PLAN_NAMES.get(pid, f"conv plan {pid}")
+            ach = s["work"] / (s["total_ms"] * 1e-3) / 1e12
+            traffic, tinfo = profiled_traffic(name, a.dtype, a.size, a.workload, a.batch)
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
-                               "frac": ach / PEAK_TFLOPS[a.dtype],
-                               "traffic": PROFILED_TRAFFIC.get((a.dtype, a.size, a.workload)) if a.batch == 1 else None,
-                               "kernel": DOMINANT_PLAN[a.dtype][1],
-                               "launches": s["launches"], "avg_launch_ms": s["avg_ms"], "measured": probe_mode}
+                               "frac": ach / PEAK_TFLOPS[a.dtype], "traffic": traffic, "traffic_source": tinfo,
+                               "kernel": name, "launches": s["launches"], "avg_launch_ms": s["avg_ms"],
+                               "share_of_conv_time": s["total_ms"] / max(1e-9, sum(Probe._sum(e)["total_ms"] for e in probe.conv.values())),
+                               "measured": probe_mode}
+        ns = probe.norm_summary()
+        if ns:
+            hb = {}
+            for kind, s in ns.items():
+                gbs = s["work"] / (s["total_ms"] * 1e-3) / 1e9
+                hb[kind] = {"kernel": "normact_fwd_kernel" if kind == "fwd" else "normact_bwd (reduce + apply)",
+                            "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "launches": s["launches"], "total_ms": s["total_ms"] / 2,
+                            "algorithmic_bytes": "2*C*V*b (read z, write a)" if kind == "fwd" else "3*C*V*b (read dy, read z, write dz; the two-kernel form executes 5 passes)"}
+            out["roofline_hbm"] = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernels": hb, "measured": probe_mode}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.size, a.workload)
+            out["cpu_baseline"] = cpu_baseline(a.size, a.workload, a.cpu_steps)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

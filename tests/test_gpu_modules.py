@@ -189,20 +189,25 @@ def test_state_dict_roundtrip_with_oracle(hip):
 
 
 def test_gan_training_step_golden(hip, golden_dir):
-    """Two full training steps at 64^3 against the goldens produced by the reference's own classes (CPU f32,
-    gan_step.npz), with float64 as the yard-stick (gan_step_f64.npz: the same two steps in f64).
+    """Two full training steps at 64^3 against the goldens produced by the reference's own classes, with float64 as the
+    yard-stick (gan_step_f64.npz: the same two steps in f64) and an ENSEMBLE of CPU f32 runs as the measure of what f32
+    rounding alone does (gan_step_f32_spread.npz: the reference classes with 1 / 2 / 3 / 4 / 8 threads and oneDNN off, i.e.
+    different f32 summation orders; per quantity the largest deviation from f64).
 
-    Step 0 is compared directly and tightly.  From the first AdamW update on, parameters move by lr * g / |g|, so rounding
-    noise in small gradients decides signs and the f32 runs drift apart -- the CPU f32 run itself is 7e-5 (losses) to 2.5e-2
-    (single parameter digests) away from f64 after step 1.  Instead of a chosen tolerance, every quantity must satisfy
+    Step 0 is compared directly and tightly with the f32 golden.  From the first AdamW update on (lr * g / |g|: rounding
+    noise decides the sign of small gradient elements -- 0.15 % of them on BOTH the CPU and the HIP side, measured against
+    f64 by tests/diag/diag_grad_noise.py) f32 runs drift apart chaotically: the step-1 adversarial loss of the CPU ensemble
+    deviates from f64 by 4e-5 ... 3.2e-3 depending on the thread count alone.  So instead of a chosen tolerance:
 
-        |hip_f32 - f64|  <=  3 * max(|cpu_f32 - f64|, class floor)
+        |hip_f32 - f64|  <=  3 * max(ensemble deviation of the quantity, class floor)
 
-    where the class floor is the largest CPU deviation among the step's losses / the median CPU deviation among the
-    network's parameter digests (a single quantity's CPU deviation can be tiny by chance)."""
+    class floor = RMS ensemble deviation of the network's parameter digests: one flipped AdamW sign in a 256-element bias
+    moves its digest by up to 1e-3 whether or not any of the 6 ensemble draws happened to flip one there (observed: HIP
+    6e-5 on upcat_4's deconv bias at step 0, ensemble 1e-5).  All quantities go to gpurun_out/f64_triangulation.log."""
     import unet_bssfp_amd as M
     from unet_bssfp_amd.gan import bSSFPToDWITensorModel, synthetic_batch
-    gold, g64 = _gold(golden_dir, "gan_step.npz"), _gold(golden_dir, "gan_step_f64.npz")
+    gold, g64, spread = (_gold(golden_dir, "gan_step.npz"), _gold(golden_dir, "gan_step_f64.npz"),
+                         _gold(golden_dir, "gan_step_f32_spread.npz"))
     torch.manual_seed(0)
     gen = M.Generator("bssfp", dropout=0.0)
     discr = M.Discriminator("bssfp")
@@ -214,56 +219,55 @@ def test_gan_training_step_golden(hip, golden_dir):
         if tag == "discr":
             return n in ("d2.conv.bias", "d3.conv.bias", "d4.conv.bias", "d5.conv.bias")
         return noisy_bias(n)
-    report = []
+    report, bad = [], []
     for step in range(2):
         model.training_step(batch, step)
-        rel = lambda v, key: abs(v - float(g64[key])) / abs(float(g64[key]))
-        cpu_dev = {gk: rel(float(gold[f"step{step}/{gk}"]), f"step{step}/{gk}") for gk in names.values()}
-        floor = max(cpu_dev.values())
         for k, gk in names.items():
+            key = f"step{step}/{gk}"
             got = float(model.last_logs[k])
             if step == 0:
-                np.testing.assert_allclose(got, gold[f"step0/{gk}"], rtol=1e-3, err_msg=k)
-            dev = rel(got, f"step{step}/{gk}")
-            report.append(f"step{step} {gk}: hip {dev:.2e} cpu {cpu_dev[gk]:.2e}")
-            assert dev <= 3 * max(cpu_dev[gk], floor) + 1e-7, (step, k, dev, cpu_dev[gk], floor)
+                np.testing.assert_allclose(got, gold[key], rtol=1e-3, err_msg=k)
+            dev = abs(got - float(g64[key])) / abs(float(g64[key]))
+            yard = float(spread[key])
+            report.append(f"{key}: hip {dev:.2e} cpu-ensemble {yard:.2e}")
+            if dev > 3 * yard + 1e-7:
+                bad.append((key, dev, yard))
         for net, tag in ((model.gen, "gen"), (model.discr, "discr")):
             items = [(n, p) for n, p in net.named_parameters() if not noisy(tag, n)]
-            cdev = {}
-            for n, _ in items:
-                key = f"step{step}/{tag}/{n}"
-                cdev[n] = abs(gold[key][1] - g64[key][1]) / max(abs(g64[key][1]), 1e-30)
-            floor = float(np.median(list(cdev.values())))
+            floor = float(np.sqrt(np.mean([float(spread[f"step{step}/{tag}/{n}"]) ** 2 for n, _ in items])))
             worst = 0.0
             for n, p in items:
                 key = f"step{step}/{tag}/{n}"
                 if abs(g64[key][1]) < 1e-12:
                     continue
-                a = p.detach().double().abs().sum().item()
-                dev = abs(a - g64[key][1]) / abs(g64[key][1])
-                worst = max(worst, dev / max(cdev[n], floor))
-                assert dev <= 3 * max(cdev[n], floor) + 1e-7, (step, tag, n, dev, cdev[n], floor)
-            report.append(f"step{step} {tag}: worst hip/cpu deviation ratio {worst:.2f} (class floor {floor:.2e})")
+                dev = abs(p.detach().double().abs().sum().item() - g64[key][1]) / abs(g64[key][1])
+                yard = max(float(spread[key]), floor)
+                worst = max(worst, dev / yard)
+                report.append(f"{key}: hip {dev:.2e} cpu-ensemble {float(spread[key]):.2e}")
+                if dev > 3 * yard + 1e-7:
+                    bad.append((key, dev, float(spread[key]), floor))
+            report.append(f"step{step} {tag}: worst hip / yard-stick ratio {worst:.2f} (class floor {floor:.2e})")
     assert all(p.requires_grad for p in model.parameters())
     model.gen.eval()
     with torch.no_grad():
         y = model.gen(batch["bssfp"]["data"])[:, :, ::4, ::4, ::4].cpu().numpy()
-    ref64 = g64["final/y_hat_eval_sample"]
-    cpu_dev = np.abs(gold["final/y_hat_eval_sample"] - ref64).mean()
-    hip_dev = np.abs(y - ref64).mean()
-    report.append(f"final eval output: hip {hip_dev:.2e} cpu {cpu_dev:.2e}")
+    hip_dev = np.abs(y - g64["final/y_hat_eval_sample"]).mean()
+    yard = float(spread["final/y_hat_eval_sample"])
+    report.append(f"final eval output (mean abs deviation from f64): hip {hip_dev:.2e} cpu-ensemble {yard:.2e}")
     try:
         with open(os.path.join(os.path.dirname(golden_dir), "..", "gpurun_out", "f64_triangulation.log"), "w") as fh:
             fh.write("\n".join(report) + "\n")
     except OSError:
         pass
-    assert hip_dev <= 3 * cpu_dev, (hip_dev, cpu_dev)
+    assert not bad, bad
+    assert hip_dev <= 3 * yard, (hip_dev, yard)
 
 
 def test_gan_step_matches_oracle_n2_s64_with_torch_adamw(hip):
     """Same step driven with torch.optim.AdamW on both sides isolates the kernels from the optimiser.  Step 0 tightly;
     step 1 (after the sign-like first AdamW update) triangulated against an f64 run of the oracle made here:
-    |hip - f64| <= 3 * max over the losses of |cpu_f32 - f64|."""
+    |hip - f64| <= 3 * max(largest |cpu_f32 - f64| among the losses, the committed ensemble spread of that loss) -- one
+    CPU run is a single draw of the chaotic drift (see test_gan_training_step_golden)."""
     import copy
     import unet_bssfp_amd as M
     from unet_bssfp_amd.gan import bSSFPToDWITensorModel, synthetic_batch
@@ -279,6 +283,7 @@ def test_gan_step_matches_oracle_n2_s64_with_torch_adamw(hip):
     x, y = R.synthetic_batch(2, 64, seed=77)
     g_opt, d_opt = R.make_optimizers(rgen, rdiscr)
     g_opt64, d_opt64 = R.make_optimizers(dgen, ddiscr)
+    spread = _gold(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"), "gan_step_f32_spread.npz")
     keys = ("gen_loss_adversarial", "gen_loss_recon_L1", "gen_loss_recon", "gen_loss", "discr_loss")
     for step in range(2):
         model.training_step(batch, step)
@@ -290,7 +295,7 @@ def test_gan_step_matches_oracle_n2_s64_with_torch_adamw(hip):
             if step == 0:
                 np.testing.assert_allclose(got, float(ref[k]), rtol=1e-3, err_msg=f"{step}/{k}")
             dev = abs(got - float(r64[k])) / abs(float(r64[k]))
-            assert dev <= 3 * cpu_dev + 1e-7, (step, k, dev, cpu_dev)
+            assert dev <= 3 * max(cpu_dev, float(spread[f"step{step}/{k}"])) + 1e-7, (step, k, dev, cpu_dev)
     # BatchNorm buffers advanced identically: head BN twice per step, PatchGAN BN three times per step
     assert int(model.gen.blocks["bssfp"].bn.num_batches_tracked) == int(rgen.blocks["bssfp"].bn.num_batches_tracked) == 4
     assert int(model.discr.d2.bn.num_batches_tracked) == int(rdiscr.d2.bn.num_batches_tracked) == 6

@@ -6,8 +6,8 @@ src/model.py).  GPU only: the package raises if the library is missing -- there 
 """
 from . import _lib  # noqa: F401
 from .nn import (BasicUNet, Conv3d, ConvTranspose3d, Discriminator, DownSampleConv, Generator,  # noqa: F401
-                 set_compute_dtype, set_default_compute_dtype)
+                 compute_dtype_from_name, set_compute_dtype, set_default_compute_dtype)
 from .functional import l1_loss  # noqa: F401
 
 __all__ = ["BasicUNet", "Conv3d", "ConvTranspose3d", "Discriminator", "DownSampleConv", "Generator",
-           "set_compute_dtype", "set_default_compute_dtype", "l1_loss"]
+           "compute_dtype_from_name", "set_compute_dtype", "set_default_compute_dtype", "l1_loss"]

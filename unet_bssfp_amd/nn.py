@@ -35,8 +35,19 @@ def set_default_compute_dtype(dtype: torch.dtype):
     _DEFAULT_DTYPE = dtype
 
 
+def compute_dtype_from_name(name):
+    """'f32' (parity mode), 'bf16' (throughput mode) -> the torch dtype ``set_compute_dtype`` takes."""
+    if isinstance(name, torch.dtype):
+        return name
+    table = {"f32": torch.float32, "fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
+    if name not in table:
+        raise ValueError(f"unknown compute dtype {name!r} (choose from {sorted(table)})")
+    return table[name]
+
+
 def set_compute_dtype(module: nn.Module, dtype: torch.dtype) -> nn.Module:
     """Arithmetic/storage type of the activations (f32: parity mode, bf16: throughput mode)."""
+    dtype = compute_dtype_from_name(dtype)
     assert dtype in (torch.float32, torch.bfloat16)
     for m in module.modules():
         if isinstance(m, _Mi355Module):

@@ -324,6 +324,18 @@ def _normact_desc(z, groups, mean, rstd, gamma, beta, slope, drop_p, seed, seed_
     return d
 
 
+# Optional launch probe (bench.py): probe(kind "fwd" | "bwd", real channels, rows, bytes per element) -> None or a callable
+# invoked right after the launches (HIP events around the fused norm + act kernels).
+NORM_PROBE = None
+
+
+def _norm_probe(kind, z, gamma):
+    if NORM_PROBE is None:
+        return None
+    n, dd, h, w, c = z.shape
+    return NORM_PROBE(kind, gamma.numel() if gamma is not None else c, n * dd * h * w, z.element_size())
+
+
 def normact_fwd(z, groups, mean, rstd, gamma, beta, slope, drop_p=0.0, seed=0, out=None, s2d=False, seed_t=None):
     """s2d=True: `out` is the pre-zeroed space-to-depth tensor S(a) (s2d_shape) instead of a plain one."""
     require_cuda(z, mean, rstd, gamma, beta, out)
@@ -334,7 +346,10 @@ def normact_fwd(z, groups, mean, rstd, gamma, beta, slope, drop_p=0.0, seed=0, o
     if s2d:
         d.s2d_a = 1
         d.sd, d.sh, d.sw = z.shape[1:4]
+    after = _norm_probe("fwd", z, gamma)
     _lib.check(_lib.load().mi355_normact_fwd(C.byref(d), _stream()), "normact_fwd")
+    if after is not None:
+        after()
     return out
 
 
@@ -356,6 +371,7 @@ def normact_bwd(z, da, groups, mean, rstd, gamma, beta, slope, drop_p, seed, bat
         d.sd, d.sh, d.sw = z.shape[1:4]
     dgamma = dbeta = None
     keep = []
+    after = _norm_probe("bwd", z, gamma)
     if mean is not None and (batch_stats or want_affine_grads):
         bpg = lib.mi355_channel_stats_blocks(rows // groups)
         part = torch.empty((groups * bpg, 2, c), dtype=torch.float32, device=z.device)
@@ -370,6 +386,8 @@ def normact_bwd(z, da, groups, mean, rstd, gamma, beta, slope, drop_p, seed, bat
         d.sums = sums.data_ptr()
         keep += [part, sums]
     _lib.check(lib.mi355_normact_bwd_apply(C.byref(d), _stream()), "normact_bwd_apply")
+    if after is not None:
+        after()
     return dz, dgamma, dbeta
 
 
