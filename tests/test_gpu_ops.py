@@ -103,6 +103,11 @@ CONV_CASES = [
     ("k3_ru_ragged_concat", 1, (32, 64), 32, (62, 66, 130), 3, 1, 1),
     ("k3_ru_ct2_n2", 2, (16,), 64, (32, 64, 64), 3, 1, 1),
     ("k3_ru_cout96", 1, (32,), 96, (64, 64, 128), 3, 1, 1),
+    # <= 32 input channels in one source, plain output grid, >= 128 footprint-segments: the marching kernel in bf16
+    ("k3_march_ragged", 1, (32,), 32, (30, 100, 140), 3, 1, 1),     # border footprints (generic march), 5-plane segments
+    ("k3_march_n2_short", 2, (32,), 32, (16, 64, 128), 3, 1, 1),    # two samples; last segment is a single plane
+    ("k3_march_cin24_cout64", 1, (24,), 64, (32, 64, 128), 3, 1, 1),  # padded input channels, two output-channel blocks
+    ("k3_march_long", 1, (32,), 32, (40, 128, 256), 3, 1, 1),       # 11-plane segments: three triples of straight-line steps
     ("k4s2", 1, (30,), 32, (8, 8, 16), 4, 2, 1),
     ("k4s2_ct2", 2, (32,), 64, (8, 8, 8), 4, 2, 1),
     ("k1_head", 2, (24,), 24, (4, 4, 8), 1, 1, 0),
@@ -147,7 +152,9 @@ def test_conv_fwd_bwd(hip, case, dtype):
     finally:
         _ops().CONV_PROBE = None
     if name.startswith("k3_ru") and dtype == torch.bfloat16:
-        assert plans and plans[0] in (31941, 31942), plans      # conv_ru_kernel<1> / <2>
+        assert plans and plans[0] in (31941, 31942, 32041), plans      # conv_ru_kernel<1> / <2> / conv_march_kernel
+    if name.startswith("k3_march") and dtype == torch.bfloat16:
+        assert plans and plans[0] == 32041, plans                      # conv_march_kernel
     close(from_act(z, cout), z_ref.detach(), dtype, "z")
     cp = z.shape[4]
     if cp > cout:                                        # pad channels must hold zeros

@@ -113,7 +113,11 @@ if __name__ == "__main__":
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default=None)
+    ap.add_argument("--lib", default=None, help="another build of the C ABI (tools/build_diag.sh)")
     a = ap.parse_args()
+    if a.lib:
+        import tools.diaglib as D
+        D.use(a.lib)
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     torch.manual_seed(0)
     if a.what in ("conv", "all"):

@@ -1,6 +1,7 @@
 // Host dispatch of the implicit-GEMM convolution kernels (C ABI: mi355_conv_fwd).
 #include <stdlib.h>
 #include "conv_kernels.h"
+#include "conv_march.h"
 
 namespace {
 
@@ -11,6 +12,7 @@ struct Plan {
   int tiles_d, tiles_h, tiles_w;
   long long tiles;
   int tiles_per_sample;
+  int seg_len, nseg;          // marching kernel (shape 10): output planes per workgroup segment, segments per sample
   int ksplit, rpb;            // split-K factor (1 = off) and rows per reduce block
   long long stat_rows;        // rows of stats_part ( = tiles, or reduce blocks under split-K )
   int stat_rows_per_sample;
@@ -23,6 +25,7 @@ int gcd_i(long long a, long long b) { while (b) { long long t = a % b; a = b; b 
 // 6 wide8 (4x4x32, 8 waves x 2 subtiles: 25 % less halo traffic than 2x4x32 at the same occupancy)
 // 7, 8: retired experiments (row reuse inside conv_halo_kernel with register staging: 216 VGPRs or spills, slower)
 // 9 ru (4x4x32, 4 waves, row-reuse loop, halo by LDS-DMA: conv_ru_kernel)
+// 10 march (16x32 footprint marching along d, 32 input channels resident: conv_march_kernel; tile extents set in make_plan)
 const int kTD[10] = {2, 2, 4, 4, 2, 2, 4, 8, 4, 4}, kTH[10] = {4, 8, 8, 4, 4, 8, 4, 4, 4, 4}, kTW[10] = {32, 16, 8, 32, 16, 8, 32, 32, 32, 32},
           kVT[10] = {2, 2, 2, 4, 1, 1, 2, 4, 4, 4};
 
@@ -62,6 +65,7 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
                   "conv: output grid exceeds the output tensor");
   }
   p->ct = (d->coutp % 64 == 0) ? 2 : 1;
+  p->seg_len = p->nseg = 0;
   p->halo = ((d->ks == 3 || d->ks == 2) && d->stride == 1);
   if (p->halo) {
     if (forced_ct() == 1) p->ct = 1;
@@ -84,6 +88,31 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
         else if (f == 6) pick = big ? 6 : 0;
         else if (f == 9) pick = 9;
         if (pick == 9 && !ru_ok) pick = big ? 6 : 0;
+        // <= 32 input channels in one source, plain output grid: the marching kernel, when its footprints x d-segments
+        // fill at least half the chip
+        const bool march_ok = ru_ok && d->c1 == 0 && d->c0 == 32 && d->os == 1 && d->ooff[0] == 0 && d->ooff[1] == 0 && d->ooff[2] == 0 &&
+                              d->pad[0] == 1 && d->pad[1] == 1 && d->pad[2] == 1 && d->do_ == d->di && d->ho == d->hi && d->wo == d->wi &&
+                              d->dy == d->do_ && d->hy == d->ho && d->wy == d->wo && (d->cstore & 7) == 0;
+        if (march_ok && (f < 0 || f == 10)) {
+          const long long fp = (long long)d->n * ceil_div(d->ho, kMarchFH) * ceil_div(d->wo, kMarchFW) * (d->coutp / 32);
+          // segment length L: the grid should be whole 256-workgroup rounds, each workgroup marches L + 2 input planes;
+          // L = 2 (mod 3), L >= 5 takes the kernel's straight-line path (conv_march.h), so only such L are proposed
+          // unless the volume is too shallow
+          long long best = -1; int best_len = 0;
+          for (int ns = 1; ns <= d->do_ && ns <= 64; ++ns) {
+            int len = ceil_div(d->do_, ns);
+            if (d->do_ >= 5) { if (len < 5) len = 5; len += (2 - len % 3 + 3) % 3; }
+            const int segs = ceil_div(d->do_, len);
+            const long long rounds = (fp * segs + 255) / 256, cost = rounds * (len + 2);
+            if (best < 0 || cost < best) { best = cost; best_len = len; }
+          }
+          const int segs = ceil_div(d->do_, best_len);
+          if (fp * segs >= 128 || f == 10) {
+            pick = 10;
+            p->seg_len = best_len;
+            p->nseg = segs;
+          }
+        }
         p->shape = pick;
       }
       // 32^3-level layers on the plain tile: one 64-channel tile per workgroup leaves <= 1 workgroup per CU on a
@@ -97,10 +126,17 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
       if (count(p->shape, p->ct) < 512) p->ct = 1;
       if (count(p->shape, p->ct) < 512) p->shape += 3;
     }
+    if (p->shape == 10) {
+      p->vt = 4; p->ct = 1;
+      p->tiles_d = p->nseg;
+      p->tiles_h = ceil_div(d->ho, kMarchFH);
+      p->tiles_w = ceil_div(d->wo, kMarchFW);
+    } else {
     p->vt = kVT[p->shape];
     p->tiles_d = ceil_div(d->do_, kTD[p->shape]);
     p->tiles_h = ceil_div(d->ho, kTH[p->shape]);
     p->tiles_w = ceil_div(d->wo, kTW[p->shape]);
+    }
     p->tiles_per_sample = p->tiles_d * p->tiles_h * p->tiles_w;
     p->tiles = (long long)p->tiles_per_sample * d->n;
   } else {
@@ -199,6 +235,13 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
           constexpr int lds = conv_halo_lds<T, 3, 4, 4, 32, 2, 8>();
           if (p.ct == 2) conv_halo_kernel<T, 3, 4, 4, 32, 2, 8><<<grid, block, lds, st>>>(a);
           else conv_halo_kernel<T, 3, 4, 4, 32, 1, 8><<<grid, block, lds, st>>>(a);
+        }
+      } else if (p.shape == 10) {
+        if constexpr (sizeof(T) == 2) {
+          static const int once = [] { return (int)hipFuncSetAttribute((const void*)conv_march_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMarchLds); }();
+          (void)once;
+          MarchArgs m{p.seg_len, p.nseg, p.tiles_h, p.tiles_w};
+          conv_march_kernel<<<grid, block, kMarchLds, st>>>(a, m);
         }
       } else if (p.shape == 9) {
         if constexpr (sizeof(T) == 2) {
