@@ -233,11 +233,20 @@ int mi355_normact_bwd_reduce(const mi355_normact_desc* d, void* stream);
 /* sums[g][2][c] = sum over blocks of part; dgamma[c] = sum_g sums[g][1][c], dbeta = sum_g sums[g][0][c] */
 int mi355_normact_bwd_finalize(const float* part, int32_t blocks_per_group, int32_t groups, int32_t c,
                                float* sums, float* dgamma, float* dbeta, void* stream);
+/* the same, writing the affine gradients straight into caller-owned gradient storage (a parameter's .grad, possibly a
+ * slice of a flat all-reduce bucket): only the first n_affine channels are written, `accumulate` adds to what is there
+ * (second use of the layer in one backward pass -- Discriminator in _discr_step, src/model.py:185-186) */
+int mi355_normact_bwd_finalize_into(const float* part, int32_t blocks_per_group, int32_t groups, int32_t c,
+                                    float* sums, float* dgamma, float* dbeta, int32_t n_affine, int32_t accumulate,
+                                    void* stream);
 int mi355_normact_bwd_apply(const mi355_normact_desc* d, void* stream);
 
 /* per-channel sum over all rows (bias gradient of a conv without normalisation):
  * out[c] = sum_rows x[row][c] from channel_stats partials (parts x [2][c]) */
 int mi355_colsum_finalize(const float* part, int32_t parts, int32_t c, float* out, void* stream);
+/* the same into caller-owned gradient storage: first n_out channels, optional accumulation */
+int mi355_colsum_finalize_into(const float* part, int32_t parts, int32_t c, float* out, int32_t n_out, int32_t accumulate,
+                               void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * MaxPool3d(kernel_size=2) -- MONAI BasicUNet `Down` (call site src/model.py:22-28).

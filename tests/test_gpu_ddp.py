@@ -1,6 +1,7 @@
 """Two ranks sharing cuda:0 over `gloo` (the box has one GPU; RCCL needs one GPU per rank): exercises the
-multi-rank code of GraphedTrainingStep (three hipGraph segments + eager all-reduce of flat gradient
-buffers) and of the eager hook-driven ddp.GradSync path on the real HIP kernels."""
+multi-rank code on the real HIP kernels -- GraphedTrainingStep (five hipGraph segments cut where a gradient bucket is
+complete, the bucket's all-reduce launched between them) and the eager path (ddp.attach: gradsink.GradBuckets launch a
+bucket's all-reduce from the backward function that completes it).  RCCL itself runs only in the driver's scaling bench."""
 import os
 import socket
 
@@ -34,12 +35,29 @@ def _worker(rank, world, port, mode, q):
         gen, discr = M.Generator("bssfp", dropout=0.0), M.Discriminator("bssfp")
         model = bSSFPToDWITensorModel("bssfp", gen=gen.to(dev), discr=discr.to(dev)).train()
         batch = synthetic_batch(2, 32, seed=70 + rank, device=dev)
+        extra = None
         if mode == "graph":
             ddp.broadcast_module_state(model.gen, 0)
             ddp.broadcast_module_state(model.discr, 0)
             step = GraphedTrainingStep(model, batch, warmup=2)
             step()
             step()
+            extra = step.launch_log
+        elif mode == "order":
+            # enqueue order of one eager step: every gradient kernel launch and every all-reduce launch, in host order
+            # (= stream order: the collective waits for what was enqueued before it and overlaps what comes after)
+            from unet_bssfp_amd import gradsink, ops
+            log = []
+            real_wgrad, real_launch = ops.conv_wgrad, gradsink.GradBuckets.launch
+            ops.conv_wgrad = lambda *a, **k: (log.append(("wgrad", None)), real_wgrad(*a, **k))[1]
+            def launch(self, b):
+                log.append(("launch", ("gen" if self is model.sinks_gen else "discr", b)))
+                return real_launch(self, b)
+            gradsink.GradBuckets.launch = launch
+            ddp.attach(model)
+            model.training_step(batch, 0)
+            ops.conv_wgrad, gradsink.GradBuckets.launch = real_wgrad, real_launch
+            extra = log
         else:
             ddp.attach(model)
             for i in range(4):
@@ -50,10 +68,10 @@ def _worker(rank, world, port, mode, q):
         dist.all_gather(gathered, digest)
         same = all(torch.equal(g, gathered[0]) for g in gathered)
         finite = bool(torch.isfinite(digest).all())
-        q.put((rank, "ok" if (same and finite) else f"FAIL same={same} finite={finite}", digest.tolist()))
+        q.put((rank, "ok" if (same and finite) else f"FAIL same={same} finite={finite}", digest.tolist(), extra))
     except Exception as e:  # noqa: BLE001
         import traceback
-        q.put((rank, f"FAIL: {e!r} {traceback.format_exc()}", None))
+        q.put((rank, f"FAIL: {e!r} {traceback.format_exc()}", None, None))
     finally:
         dist.destroy_process_group()
 
@@ -74,10 +92,31 @@ def _run(mode):
 def test_graph_segments_with_eager_allreduce_two_ranks(hip):
     res = _run("graph")
     assert all(r[1] == "ok" for r in res), [r[1] for r in res]
+    # the late buckets are exchanged between the two backward stages of their phase
+    assert res[0][3] == [("allreduce gen[0]", "before gen backward stage 2"), ("allreduce discr[0]", "before discr backward stage 2")]
+
+
+def test_allreduce_of_bucket0_is_enqueued_before_the_last_backward_kernels(hip):
+    """src/train.py:30-32 (DDP overlaps the gradient all-reduce with backward): in the eager step the all-reduce of each
+    network's bucket 0 (the layers whose gradients are ready first) must be enqueued BEFORE the weight-gradient kernels of
+    the remaining layers -- stream order decides what it can overlap -- and bucket 1 after them."""
+    res = _run("order")
+    assert all(r[1] == "ok" for r in res), [r[1] for r in res]
+    for r in res:
+        log = r[3]
+        pos = {e[1]: i for i, e in enumerate(log) if e[0] == "launch"}
+        wg = [i for i, e in enumerate(log) if e[0] == "wgrad"]
+        assert set(pos) == {("gen", 0), ("gen", 1), ("discr", 0), ("discr", 1)}, pos
+        gen_wg = [i for i in wg if i < pos[("gen", 1)]]
+        discr_wg = [i for i in wg if pos[("gen", 1)] < i < pos[("discr", 1)]]
+        # weight-gradient kernels follow the launch of bucket 0 in both phases: there is backward work left to overlap
+        assert pos[("gen", 0)] < gen_wg[-1] and sum(i > pos[("gen", 0)] for i in gen_wg) >= 4, (pos, gen_wg)
+        assert pos[("discr", 0)] < discr_wg[-1] and sum(i > pos[("discr", 0)] for i in discr_wg) >= 2, (pos, discr_wg)
 
 
 def test_graph_and_hook_paths_agree_two_ranks(hip):
-    """Same 4 steps through (a) hipGraph segments + flat all-reduce and (b) eager GradSync hooks."""
+    """Same 4 steps through (a) hipGraph segments with the exchanges between them and (b) the eager step whose backward
+    functions launch the exchanges: identical kernels, identical buckets -> identical parameters."""
     a, b = _run("graph"), _run("eager")
     assert all(r[1] == "ok" for r in a + b), [r[1] for r in a + b]
     da, db = torch.tensor(a[0][2]), torch.tensor(b[0][2])

@@ -437,6 +437,45 @@ def test_hipgraph_replayed_step_equals_eager_step(hip):
         assert torch.equal(p, q), n
     for k in ("train_gen_loss", "train_discr_loss"):
         assert float(eager.last_logs[k]) == float(graphed.last_logs[k])
+    # the multi-rank structure (five segments, two-stage backward passes cut at the marked activations) on one rank
+    seg = build()
+    gs2 = GraphedTrainingStep(seg, batch, warmup=2, force_segments=True)
+    assert len(gs2.graphs) == 5
+    gs2()
+    gs2()
+    torch.cuda.synchronize()
+    for (n, p), (_, q) in zip(eager.named_parameters(), seg.named_parameters()):
+        assert torch.equal(p, q), n
     g_opt, _ = graphed.optimizers()
     g_opt.sync_step_counts()
     assert g_opt.state[graphed.gen.blocks["unet"].final_conv.weight]["step"] == 4
+
+
+def test_gradient_sinks_equal_autograd_accumulation(hip):
+    """gradsink.GradBuckets (gradient kernels write parameter gradients in place, second uses accumulate in the kernel) must
+    give the same gradients and the same parameters after two steps as plain autograd accumulation (.grad tensors created by
+    AccumulateGrad, duplicate uses summed by the engine): same kernels, so bit-identical except where the discriminator's
+    two contributions are added in a different order (in-kernel accumulate vs engine add: commutative, still identical)."""
+    import unet_bssfp_amd as M
+    from unet_bssfp_amd.functional import DropoutState
+    from unet_bssfp_amd.gan import bSSFPToDWITensorModel, synthetic_batch
+    batch = synthetic_batch(2, 32, seed=3, device=DEV)
+    out = []
+    for sinks in (True, False):
+        torch.manual_seed(6)
+        DropoutState.reset()
+        model = bSSFPToDWITensorModel("bssfp", gen=M.Generator("bssfp", dropout=0.05).to(DEV), discr=M.Discriminator("bssfp").to(DEV)).train()
+        model.use_grad_sinks = sinks
+        for i in range(2):
+            model.training_step(batch, i)
+        assert (model.sinks_gen is not None) == sinks
+        out.append(([p.detach().clone() for p in model.parameters()], {k: float(v) for k, v in model.last_logs.items()}))
+        if sinks:
+            assert model.sinks_gen.complete() and model.sinks_discr.complete()
+            # every used parameter's .grad is a view of its bucket
+            flat = model.sinks_gen.flat[0]
+            p0 = model.sinks_gen.params[0][0]
+            assert flat.data_ptr() <= p0.grad.data_ptr() < flat.data_ptr() + flat.numel() * 4
+    for a, b in zip(out[0][0], out[1][0]):
+        assert torch.equal(a, b)
+    assert out[0][1] == out[1][1]

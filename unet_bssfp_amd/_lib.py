@@ -79,8 +79,10 @@ _SIGNATURES = {
     "mi355_normact_fwd": (C.c_int, [C.POINTER(NormActDesc), _vp]),
     "mi355_normact_bwd_reduce": (C.c_int, [C.POINTER(NormActDesc), _vp]),
     "mi355_normact_bwd_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "mi355_normact_bwd_finalize_into": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp]),
     "mi355_normact_bwd_apply": (C.c_int, [C.POINTER(NormActDesc), _vp]),
     "mi355_colsum_finalize": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "mi355_colsum_finalize_into": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp]),
     "mi355_maxpool2_fwd": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mi355_maxpool2_bwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mi355_maxpool2_bwd_add": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

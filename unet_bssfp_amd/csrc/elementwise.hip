@@ -239,12 +239,12 @@ __global__ __launch_bounds__(1024) void norm_finalize_kernel(const float* __rest
 }
 
 __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ part, int parts, int c,
-                                                               float* __restrict__ out) {
+                                                               float* __restrict__ out, int n_out, int accumulate) {
   const int ch0 = blockIdx.x * 8;
   double s0, s1;
   block_sum_parts(part, parts, c, ch0, s0, s1);
   const int ch = ch0 + (int)threadIdx.x;
-  if (threadIdx.x < 8 && ch < c) out[ch] = (float)s0;
+  if (threadIdx.x < 8 && ch < n_out) out[ch] = accumulate ? out[ch] + (float)s0 : (float)s0;
 }
 
 // ------------------------------------------------------------------ norm + dropout + LeakyReLU
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void normact_bwd_reduce_kernel(const NormActAr
 
 __global__ __launch_bounds__(1024) void normact_bwd_finalize_kernel(const float* __restrict__ part, int bpg,
                                                                     int groups, int c, float* __restrict__ sums,
-                                                                    float* dgamma, float* dbeta) {
+                                                                    float* dgamma, float* dbeta, int n_affine, int accumulate) {
   const int ch0 = blockIdx.x * 8;
   const int ch = ch0 + (int)threadIdx.x;
   const bool owner = threadIdx.x < 8 && ch < c;
@@ -404,9 +404,9 @@ __global__ __launch_bounds__(1024) void normact_bwd_finalize_kernel(const float*
       tg += s1;
     }
   }
-  if (owner) {
-    if (dgamma) dgamma[ch] = (float)tg;
-    if (dbeta) dbeta[ch] = (float)tb;
+  if (owner && ch < n_affine) {
+    if (dgamma) dgamma[ch] = accumulate ? dgamma[ch] + (float)tg : (float)tg;
+    if (dbeta) dbeta[ch] = accumulate ? dbeta[ch] + (float)tb : (float)tb;
   }
 }
 
@@ -954,8 +954,13 @@ int mi355_norm_finalize(const float* part, int32_t parts_per_group, int32_t grou
 }
 
 int mi355_colsum_finalize(const float* part, int32_t parts, int32_t c, float* out, void* stream) {
-  MI355_REQUIRE(part && out && parts > 0 && c > 0, "colsum_finalize: bad argument");
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((c + 7) / 8), dim3(1024), 0, (hipStream_t)stream, part, parts, c, out);
+  return mi355_colsum_finalize_into(part, parts, c, out, c, 0, stream);
+}
+
+int mi355_colsum_finalize_into(const float* part, int32_t parts, int32_t c, float* out, int32_t n_out, int32_t accumulate,
+                               void* stream) {
+  MI355_REQUIRE(part && out && parts > 0 && c > 0 && n_out > 0 && n_out <= c, "colsum_finalize: bad argument");
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((c + 7) / 8), dim3(1024), 0, (hipStream_t)stream, part, parts, c, out, n_out, accumulate);
   return mi355_check_launch("colsum_finalize");
 }
 
@@ -1034,9 +1039,15 @@ int mi355_normact_bwd_reduce(const mi355_normact_desc* d, void* stream) {
 
 int mi355_normact_bwd_finalize(const float* part, int32_t blocks_per_group, int32_t groups, int32_t c, float* sums,
                                float* dgamma, float* dbeta, void* stream) {
-  MI355_REQUIRE(part && sums && blocks_per_group > 0 && groups > 0 && c > 0, "normact_bwd_finalize: bad argument");
+  return mi355_normact_bwd_finalize_into(part, blocks_per_group, groups, c, sums, dgamma, dbeta, c, 0, stream);
+}
+
+int mi355_normact_bwd_finalize_into(const float* part, int32_t blocks_per_group, int32_t groups, int32_t c, float* sums,
+                                    float* dgamma, float* dbeta, int32_t n_affine, int32_t accumulate, void* stream) {
+  MI355_REQUIRE(part && sums && blocks_per_group > 0 && groups > 0 && c > 0 && n_affine > 0 && n_affine <= c,
+                "normact_bwd_finalize: bad argument");
   hipLaunchKernelGGL(normact_bwd_finalize_kernel, dim3((c + 7) / 8), dim3(1024), 0, (hipStream_t)stream, part,
-                     blocks_per_group, groups, c, sums, dgamma, dbeta);
+                     blocks_per_group, groups, c, sums, dgamma, dbeta, n_affine, accumulate);
   return mi355_check_launch("normact_bwd_finalize");
 }
 

@@ -164,9 +164,23 @@ def attach(model, bucket_mb: float = 25.0, group=None, broadcast: bool = True):
         broadcast_module_state(model.gen, 0, group)
         broadcast_module_state(model.discr, 0, group)
     modality = getattr(model, "input_modality", None)
+    if getattr(model, "enable_grad_sinks", None) is not None and model.enable_grad_sinks(group):
+        # HIP networks: the gradient kernels write into flat per-stage buckets (gradsink.py); a bucket is all-reduced the
+        # moment its last gradient kernel has been enqueued, under the rest of the backward pass
+        return model
     model.grad_sync_gen = GradSync(used_parameters(model.gen, modality), bucket_mb, group)
     model.grad_sync_discr = GradSync(used_parameters(model.discr, modality), bucket_mb, group)
     return model
+
+
+def broadcast_buffers(model, every: int = 1, step: int = 0, group=None):
+    """DDP's ``broadcast_buffers=True`` (implied by src/train.py:30): rank 0's BatchNorm running statistics to every rank.
+    The statistics are computed per rank (no SyncBatchNorm, as in the reference), so without this the eval-mode outputs
+    of the generator head and of the PatchGAN drift apart between ranks.  ``every`` = k broadcasts only every k-th step
+    (the buffers are ~8 KB; k = 1 reproduces DDP's per-forward broadcast at step granularity)."""
+    if every > 0 and step % every == 0:
+        broadcast_module_state(model.gen, 0, group, buffers_only=True)
+        broadcast_module_state(model.discr, 0, group, buffers_only=True)
 
 
 def used_parameters(net: torch.nn.Module, modality) -> List[torch.nn.Parameter]:

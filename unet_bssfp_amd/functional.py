@@ -14,6 +14,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import ops
+from .gradsink import sink_of
 from .ops import round_up
 
 CLASSES8 = [(a, b, c) for a in (0, 1) for b in (0, 1) for c in (0, 1)]
@@ -97,6 +98,32 @@ def _padded(vec: Optional[torch.Tensor], n: int, fill: float = 0.0) -> Optional[
     out = torch.full((n,), fill, dtype=torch.float32, device=v.device)
     out[: v.numel()] = v
     return out
+
+
+# ====================================================================================== backward stages
+class StageBoundary:
+    """Collects, during a forward pass, the activations at which the backward pass can be cut into two stages (late
+    layers first, early layers second) so that the late stage's gradient bucket is exchanged while the early stage's
+    backward kernels run (gan.GraphedTrainingStep).  Inactive unless ``begin()`` was called."""
+    _active = None
+
+    @classmethod
+    def begin(cls):
+        cls._active = []
+
+    @classmethod
+    def active(cls) -> bool:
+        return cls._active is not None
+
+    @classmethod
+    def mark(cls, *tensors):
+        if cls._active is not None:
+            cls._active.extend(t for t in tensors if t is not None and t.requires_grad)
+
+    @classmethod
+    def end(cls):
+        out, cls._active = cls._active or [], None
+        return out
 
 
 # ====================================================================================== layout
@@ -325,6 +352,7 @@ class ConvFn(Function):
         ctx.save_for_backward(x0, x1, weight)
         ctx.spec = spec
         ctx.has_bias = bias is not None
+        ctx.bias_param, ctx.weight_param = bias, weight    # (their .grad may live in a GradBuckets buffer: gradsink.py)
         # a normalisation with batch/instance statistics follows: the mean subtraction cancels the bias,
         # so its gradient is identically zero and is returned as exact zeros (no reduction pass)
         ctx.zero_bias_grad = zero_bias_grad
@@ -373,25 +401,41 @@ class ConvFn(Function):
             dx0 = dxc[..., :c0] if c1 else dxc
             dx1 = dxc[..., c0:] if c1 else None
         if ctx.needs_input_grad[2]:
-            dw = torch.empty_like(weight, dtype=torch.float32)
+            # gradient storage owned by the path (gradsink.GradBuckets): the kernel writes (or, for a second use of the
+            # layer in this backward pass, accumulates) straight into weight.grad and autograd gets None
+            weight = ctx.weight_param
+            wsink = sink_of(weight)
+            acc = wsink is not None and not wsink.fresh(weight)
+            dwt = weight.grad if wsink is not None else torch.empty_like(weight, dtype=torch.float32)
             if ctx.s2d_cp:
-                ops.conv_wgrad(x0, None, dz, (do_, ho, wo), 1, (0, 0, 0), 2, 1, (0, 0, 0), dw, spec.cout, spec.cin,
-                               spec.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (2, 2, 2), s2d_cp=ctx.s2d_cp)
+                ops.conv_wgrad(x0, None, dz, (do_, ho, wo), 1, (0, 0, 0), 2, 1, (0, 0, 0), dwt, spec.cout, spec.cin,
+                               spec.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (2, 2, 2), s2d_cp=ctx.s2d_cp, accumulate=acc)
             elif spec.kind == "conv":
-                ops.conv_wgrad(x0, x1, dz, (do_, ho, wo), 1, (0, 0, 0), k, spec.stride, (spec.pad,) * 3, dw,
-                               spec.cout, spec.cin, spec.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (1, 1, 1))
+                ops.conv_wgrad(x0, x1, dz, (do_, ho, wo), 1, (0, 0, 0), k, spec.stride, (spec.pad,) * 3, dwt,
+                               spec.cout, spec.cin, spec.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (1, 1, 1), accumulate=acc)
             elif dtype == torch.bfloat16 and spec.cout % 32 == 0 and cg == spec.cout:
                 # transposed conv: the 8 classes are 8*Cout GEMM columns of one k=1 weight-gradient launch
-                ops.conv_wgrad(x0, None, dz, (di, hi, wi), 1, (0, 0, 0), 1, 1, (0, 0, 0), dw,
+                ops.conv_wgrad(x0, None, dz, (di, hi, wi), 1, (0, 0, 0), 1, 1, (0, 0, 0), dwt,
                                spec.cout, spec.cin, 8, spec.cout * 8, (4, 2, 1), (0, 0, 0), (0, 0, 0),
-                               g_cls_cout=spec.cout)
+                               g_cls_cout=spec.cout, accumulate=acc)
             else:
                 for cls in CLASSES8:
-                    ops.conv_wgrad(x0, None, dz, (di, hi, wi), 2, cls, 1, 1, (0, 0, 0), dw,
-                                   spec.cout, spec.cin, 8, spec.cout * 8, (4, 2, 1), cls, (0, 0, 0))
+                    ops.conv_wgrad(x0, None, dz, (di, hi, wi), 2, cls, 1, 1, (0, 0, 0), dwt,
+                                   spec.cout, spec.cin, 8, spec.cout * 8, (4, 2, 1), cls, (0, 0, 0), accumulate=acc)
+            if wsink is not None:
+                wsink.written(weight)
+            else:
+                dw = dwt
         if ctx.has_bias and ctx.needs_input_grad[3]:
+            bsink = sink_of(ctx.bias_param)
             if ctx.zero_bias_grad:
-                db = _cached_zeros(spec.cout, dev)
+                if bsink is not None:
+                    bsink.written(ctx.bias_param)          # its slice of the bucket is zero and nobody ever writes it
+                else:
+                    db = _cached_zeros(spec.cout, dev)
+            elif bsink is not None:
+                ops.colsum_into(dz, ctx.bias_param.grad, accumulate=not bsink.fresh(ctx.bias_param))
+                bsink.written(ctx.bias_param)
             else:
                 db = ops.colsum(dz)[: spec.cout].contiguous()
         return dx0, dx1, dw, db, None, None, None, None
@@ -483,6 +527,7 @@ class NormActFn(Function):
             a = ops.normact_fwd(z, groups, mean, rstd, gp, bp, cfg.slope, p, seed, seed_t=seed_t)
         ctx.s2d_out = s2d_out
         ctx.seed_t = seed_t
+        ctx.affine_params = (gamma, beta)
         ctx.save_for_backward(z, mean, rstd, gp, bp)
         ctx.meta = (groups, cfg.slope, p, seed, batch_stats, gamma.numel() if gamma is not None else 0)
         return a
@@ -494,6 +539,16 @@ class NormActFn(Function):
         groups, slope, p, seed, batch_stats, nch = ctx.meta
         da = ops.as_act(da)
         want_affine = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        gamma_p, beta_p = ctx.affine_params
+        sink = sink_of(gamma_p) if (ctx.needs_input_grad[2] and ctx.needs_input_grad[3] and mean is not None) else None
+        if sink is not None and sink_of(beta_p) is sink:
+            # both affine gradients straight into the parameters' .grad storage (gradsink.py)
+            dz, _, _ = ops.normact_bwd(z, da, groups, mean, rstd, gp, bp, slope, p, seed, batch_stats, True,
+                                       s2d=ctx.s2d_out, seed_t=ctx.seed_t, affine_into=(gamma_p.grad, beta_p.grad),
+                                       accumulate=not sink.fresh(gamma_p))
+            sink.written(gamma_p)
+            sink.written(beta_p)
+            return dz, None, None, None, None, None, None, None, None, None, None
         dz, dgamma, dbeta = ops.normact_bwd(z, da, groups, mean, rstd, gp, bp, slope, p, seed, batch_stats,
                                             want_affine and mean is not None, s2d=ctx.s2d_out, seed_t=ctx.seed_t)
         dg = dgamma[:nch].contiguous() if (dgamma is not None and ctx.needs_input_grad[2]) else None

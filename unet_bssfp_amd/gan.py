@@ -59,6 +59,10 @@ class bSSFPToDWITensorModel(nn.Module):
         self.reference_quirks = reference_quirks
         self.grad_sync_gen = None      # set by ddp.attach(); called after each phase's backward
         self.grad_sync_discr = None
+        self.sinks_gen = None          # gradsink.GradBuckets of the HIP networks (created at the first training step)
+        self.sinks_discr = None
+        self.use_grad_sinks = True
+        self._stage = None
         self._optimizers = None
         self.last_logs: Dict[str, torch.Tensor] = {}
 
@@ -131,48 +135,111 @@ class bSSFPToDWITensorModel(nn.Module):
         for p in module.parameters():
             p.requires_grad_(flag)
 
-    # The step is split at the two points where gradients cross ranks, so that it can run eagerly
+    # ------------------------------------------------------------------ gradient storage / exchange
+    def enable_grad_sinks(self, group=None) -> bool:
+        """HIP networks on the GPU: parameter gradients live in flat per-stage buckets that the gradient kernels write
+        in place (gradsink.py).  Bucket 0 = the layers whose gradients are ready first (decoder + bottleneck of the
+        U-Net; d3..final of the PatchGAN), bucket 1 = the rest; with world size > 1 a bucket is all-reduced as soon as
+        it is complete, under the remaining backward kernels."""
+        if self.sinks_gen is not None:
+            return True
+        if not self.use_grad_sinks:
+            return False
+        from .nn import Discriminator, Generator, backward_stages
+        if not (isinstance(self.gen, Generator) and isinstance(self.discr, Discriminator) and next(self.gen.parameters()).is_cuda):
+            return False
+        from .gradsink import GradBuckets
+        self.sinks_gen = GradBuckets(backward_stages(self.gen, self.input_modality), group, uses_per_phase=1)
+        self.sinks_discr = GradBuckets(backward_stages(self.discr, self.input_modality), group, uses_per_phase=2)
+        return True
+
+    def _finish_grads(self, which: str):
+        sinks = self.sinks_gen if which == "gen" else self.sinks_discr
+        sync = self.grad_sync_gen if which == "gen" else self.grad_sync_discr
+        if sinks is not None:
+            sinks.finish()
+        elif sync is not None:
+            sync.finish()
+
+    def _backward(self, loss, staged: bool):
+        """``manual_backward``.  staged: only the late stage (down to the activations marked by Fn.StageBoundary); the
+        early stage follows in ``_backward_early`` -- the caller exchanges the late bucket in between."""
+        if not staged:
+            loss.backward()
+            return
+        from .functional import StageBoundary
+        boundary = StageBoundary.end()
+        sinks = self._stage_sinks
+        late = [p for p in sinks.params[0] if p.requires_grad]
+        grads = torch.autograd.grad([loss], boundary + late, retain_graph=True, allow_unused=True)
+        assert all(g is None for g in grads[len(boundary):]), "staged backward needs gradient sinks"
+        self._stage = (boundary, list(grads[: len(boundary)]), [p for p in sinks.params[1] if p.requires_grad])
+
+    def _backward_early(self):
+        boundary, grads, early = self._stage
+        self._stage = None
+        torch.autograd.backward(boundary, grads, inputs=early)
+
+    # The step is split at the points where gradients cross ranks, so that it can run eagerly
     # (training_step) or as hipGraph segments with the collectives in between (GraphedTrainingStep).
-    def _phase_gen(self, batch, logs):
+    def _phase_gen(self, batch, logs, staged=False):
         """toggle(gen_opt) -> _gen_step -> manual_backward          (src/model.py:264-268)"""
         x, y = self.unpack_batch(batch)
         if x.is_cuda:
-            from .functional import DropoutState
+            from .functional import DropoutState, StageBoundary
             DropoutState.advance(x.device)
+            if self.enable_grad_sinks():
+                self.sinks_gen.begin_phase(1)
+            if staged:
+                self._stage_sinks = self.sinks_gen
+                StageBoundary.begin()
         self._toggle(self.discr, False)
         loss, _ = self._gen_step(x, y, logs)
         logs["train_gen_loss"] = loss.detach()
-        loss.backward()
+        self._backward(loss, staged)
 
-    def _phase_gen_update_discr(self, batch, logs):
-        """gen_opt.step/zero_grad/untoggle -> toggle(discr_opt) -> _discr_step -> manual_backward  (:269-278)"""
-        x, y = self.unpack_batch(batch)
+    def _update_gen(self):
+        """gen_opt.step/zero_grad/untoggle                             (:269-271)"""
         gen_opt, _ = self.optimizers()
         gen_opt.step()
-        gen_opt.zero_grad()
+        if self.sinks_gen is None:
+            gen_opt.zero_grad()             # (gradient sinks are never zeroed: the next phase's first write overwrites)
         self._repack(self.gen)
         self._toggle(self.discr, True)
+
+    def _phase_discr(self, batch, logs, staged=False):
+        """toggle(discr_opt) -> _discr_step -> manual_backward         (:274-278)"""
+        x, y = self.unpack_batch(batch)
         self._toggle(self.gen, False)
+        if self.sinks_discr is not None:
+            self.sinks_discr.begin_phase(2)
+        if staged:
+            from .functional import StageBoundary
+            self._stage_sinks = self.sinks_discr
+            StageBoundary.begin()
         loss = self._discr_step(x, y)
         logs["train_discr_loss"] = loss.detach()
-        loss.backward()
+        self._backward(loss, staged)
+
+    def _phase_gen_update_discr(self, batch, logs):
+        self._update_gen()
+        self._phase_discr(batch, logs)
 
     def _phase_discr_update(self):
         """discr_opt.step/zero_grad/untoggle                          (:279-281)"""
         _, discr_opt = self.optimizers()
         discr_opt.step()
-        discr_opt.zero_grad()
+        if self.sinks_discr is None:
+            discr_opt.zero_grad()
         self._repack(self.discr)
         self._toggle(self.gen, True)
 
     def training_step(self, batch, batch_idx=0):
         logs: Dict[str, torch.Tensor] = {}
         self._phase_gen(batch, logs)
-        if self.grad_sync_gen is not None:
-            self.grad_sync_gen.finish()
+        self._finish_grads("gen")
         self._phase_gen_update_discr(batch, logs)
-        if self.grad_sync_discr is not None:
-            self.grad_sync_discr.finish()
+        self._finish_grads("discr")
         self._phase_discr_update()
         self.last_logs = logs
         return None
@@ -254,37 +321,50 @@ class bSSFPToDWITensorModel(nn.Module):
 
 
 class GraphedTrainingStep:
-    """The training step as hipGraph replays (HIP graphs instead of ~1 000 eager launches per step).
+    """The training step as hipGraph replays (HIP graphs instead of ~600 eager launches per step).
 
-    world_size 1: the whole step is one graph.  world_size > 1: three graph segments with the two
-    gradient all-reduces (generator, discriminator) issued eagerly between them on flat buffers --
-    the payload (90.6 MB + 44.9 MB f32) is ~1 ms on xGMI against a ~20 ms step, so it is not
-    overlapped here; the hook-driven overlapped path is ``ddp.GradSync`` (eager mode).
+    world_size 1: the whole step is one graph.
+
+    world_size > 1 (src/train.py:30-32 -- DDP's bucketed all-reduce overlapped with backward): the step is FIVE
+    graph segments cut where a gradient bucket is complete; each bucket lives in one flat buffer that the gradient
+    kernels write in place (gradsink.py: no gather / scatter copies), and its all-reduce is launched asynchronously
+    right after the segment that completes it has been enqueued, so RCCL (its own stream, xGMI) runs UNDER the next
+    segment's backward kernels:
+
+        [G fwd, D fwd, backward of D + U-Net decoder / bottleneck]   -> all-reduce gen bucket 0 (84 MB)  ...
+        [backward of down_2, down_1, conv_0, head (full resolution)] -> all-reduce gen bucket 1          ... wait
+        [gen AdamW, G fwd, D fwd x2, backward of final, d5, d4, d3]  -> all-reduce discr bucket 0 (44 MB) ...
+        [backward of d2, d1 (the full-resolution PatchGAN layers)]   -> all-reduce discr bucket 1        ... wait
+        [discr AdamW]
+
+    The cut points are activations marked during the forward pass (Fn.StageBoundary); the two backward stages are
+    ``torch.autograd.grad`` down to them and ``torch.autograd.backward`` from them.
 
     The batch tensors are static inputs: ``load(batch)`` copies new volumes into them.  Dropout masks
     change per replay (device-side step counter), AdamW bias correction advances on the device.
     """
 
-    def __init__(self, model: bSSFPToDWITensorModel, batch, warmup: int = 3, group=None):
+    def __init__(self, model: bSSFPToDWITensorModel, batch, warmup: int = 3, group=None, force_segments: bool = False):
         import torch.distributed as dist
-        from .ddp import used_parameters
         self.model = model
         self.batch = batch
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.segmented = self.world > 1 or force_segments      # (force_segments: the multi-rank structure on one rank, for tests)
         if model.grad_sync_gen is not None or model.grad_sync_discr is not None:
             raise RuntimeError("GraphedTrainingStep does its own gradient exchange: do not ddp.attach() the model")
-        self._gparams = used_parameters(model.gen, model.input_modality)
-        self._dparams = used_parameters(model.discr, model.input_modality)
-        dev = next(model.parameters()).device
-        self._flat_g = torch.zeros(sum(p.numel() for p in self._gparams), device=dev) if self.world > 1 else None
-        self._flat_d = torch.zeros(sum(p.numel() for p in self._dparams), device=dev) if self.world > 1 else None
+        if self.segmented:
+            if not model.enable_grad_sinks(group):
+                raise RuntimeError("GraphedTrainingStep with world size > 1 needs the HIP networks on the GPU")
+            model.sinks_gen.auto_launch = model.sinks_discr.auto_launch = False      # launched between the segments
+        self.launch_log = []                                # (what, position) of the latest step: tests
         for _ in range(max(2, warmup)):                     # eager: allocations, caches, optimiser state
             self._eager_step()
         torch.cuda.synchronize()
         self.graphs = []
-        logs: Dict[str, torch.Tensor] = {}
-        if self.world == 1:
+        self.logs: Dict[str, torch.Tensor] = {}
+        logs = self.logs
+        if not self.segmented:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 model._phase_gen(batch, logs)
@@ -292,59 +372,57 @@ class GraphedTrainingStep:
                 model._phase_discr_update()
             self.graphs = [g]
         else:
-            g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                model._phase_gen(batch, logs)
-                self._gather(self._gparams, self._flat_g)
-            with torch.cuda.graph(g2, pool=g1.pool()):
-                self._scatter(self._gparams, self._flat_g)
-                model._phase_gen_update_discr(batch, logs)
-                self._gather(self._dparams, self._flat_d)
-            with torch.cuda.graph(g3, pool=g1.pool()):
-                self._scatter(self._dparams, self._flat_d)
+            gs = [torch.cuda.CUDAGraph() for _ in range(5)]
+            with torch.cuda.graph(gs[0]):
+                model._phase_gen(batch, logs, staged=True)
+            with torch.cuda.graph(gs[1], pool=gs[0].pool()):
+                model._backward_early()
+            with torch.cuda.graph(gs[2], pool=gs[0].pool()):
+                model._update_gen()
+                model._phase_discr(batch, logs, staged=True)
+            with torch.cuda.graph(gs[3], pool=gs[0].pool()):
+                model._backward_early()
+            with torch.cuda.graph(gs[4], pool=gs[0].pool()):
                 model._phase_discr_update()
-            self.graphs = [g1, g2, g3]
+            self.graphs = gs
         model.last_logs = logs
         torch.cuda.synchronize()
 
-    # ---- flat gradient buffers (world > 1)
-    @staticmethod
-    def _gather(params, flat):
-        off = 0
-        for p in params:
-            n = p.numel()
-            if p.grad is not None:
-                flat[off:off + n].copy_(p.grad.reshape(-1))
-            else:
-                flat[off:off + n].zero_()
-            off += n
-
-    def _scatter(self, params, flat):
-        flat.mul_(1.0 / self.world)
-        off = 0
-        for p in params:
-            n = p.numel()
-            p.grad = flat[off:off + n].view_as(p)
-            off += n
-
-    def _reduce(self, flat):
-        import torch.distributed as dist
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+    def _segments(self, run):
+        """The multi-rank step: ``run(i)`` executes segment i (eagerly or as a graph replay)."""
+        m = self.model
+        self.launch_log = []
+        run(0)
+        m.sinks_gen.launch(0); self.launch_log.append(("allreduce gen[0]", "before gen backward stage 2"))
+        run(1)
+        m.sinks_gen.launch(1)
+        m.sinks_gen.finish()
+        run(2)
+        m.sinks_discr.launch(0); self.launch_log.append(("allreduce discr[0]", "before discr backward stage 2"))
+        run(3)
+        m.sinks_discr.launch(1)
+        m.sinks_discr.finish()
+        run(4)
 
     def _eager_step(self):
         m = self.model
         logs: Dict[str, torch.Tensor] = {}
-        m._phase_gen(self.batch, logs)
-        if self.world > 1:
-            self._gather(self._gparams, self._flat_g)
-            self._reduce(self._flat_g)
-            self._scatter(self._gparams, self._flat_g)
-        m._phase_gen_update_discr(self.batch, logs)
-        if self.world > 1:
-            self._gather(self._dparams, self._flat_d)
-            self._reduce(self._flat_d)
-            self._scatter(self._dparams, self._flat_d)
-        m._phase_discr_update()
+        if not self.segmented:
+            m._phase_gen(self.batch, logs)
+            m._phase_gen_update_discr(self.batch, logs)
+            m._phase_discr_update()
+        else:
+            def run(i):
+                if i == 0:
+                    m._phase_gen(self.batch, logs, staged=True)
+                elif i == 1 or i == 3:
+                    m._backward_early()
+                elif i == 2:
+                    m._update_gen()
+                    m._phase_discr(self.batch, logs, staged=True)
+                else:
+                    m._phase_discr_update()
+            self._segments(run)
         m.last_logs = logs
 
     def load(self, batch):
@@ -354,15 +432,11 @@ class GraphedTrainingStep:
                 self.batch[k][DATA].copy_(v[DATA], non_blocking=True)
 
     def __call__(self):
-        if self.world == 1:
+        if not self.segmented:
             self.graphs[0].replay()
-            return
-        g1, g2, g3 = self.graphs
-        g1.replay()
-        self._reduce(self._flat_g)
-        g2.replay()
-        self._reduce(self._flat_d)
-        g3.replay()
+        else:
+            self._segments(lambda i: self.graphs[i].replay())
+        self.model.last_logs = self.logs
 
 
 def synthetic_batch(n: int, s, seed: int, modality: str = "bssfp", device="cpu"):

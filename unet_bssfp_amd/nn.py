@@ -221,10 +221,14 @@ class Discriminator(_Mi355Module):
             for i, blk in enumerate(blocks):
                 h = blk.forward_act(h, s2d_cp=cp, s2d_out=i < 4)
                 cp = round_up(blk.conv.out_channels, 16)
+                if i == 1 and blk.conv.weight.requires_grad:                    # (not while D is frozen in the generator phase)
+                    Fn.StageBoundary.mark(h)                            # backward stage cut: {final, d5, d4, d3} | {d2, d1}
         else:
             h = Fn.PackFn.apply(cp, self.compute_dtype, x, y)           # torch.cat([x, y], 1) + layout
-            for blk in blocks:
+            for i, blk in enumerate(blocks):
                 h = blk.forward_act(h)
+                if i == 1 and blk.conv.weight.requires_grad:
+                    Fn.StageBoundary.mark(h)
         z, _ = self.final.forward_act(h)
         return Fn.UnpackFn.apply(z, 1)
 
@@ -337,6 +341,12 @@ class BasicUNet(_Mi355Module):
         x0 = self.conv_0.forward_act(x)
         s0, x1 = self.down_1.forward_skip(x0)
         s1, x2 = self.down_2.forward_skip(x1)
+        if Fn.StageBoundary.active():
+            # backward stage cut: everything from down_3 on | {down_2, down_1, conv_0, head}.  The skip tensors get a node of
+            # their own: a gradient captured AT the two-output SkipPoolFn node would make autograd execute every path
+            # into that node -- the pooled branch through down_1 / down_2 included -- already in the first stage.
+            s0, s1 = s0.view_as(s0), s1.view_as(s1)
+            Fn.StageBoundary.mark(x2, s1, s0)
         s2, x3 = self.down_3.forward_skip(x2)
         s3, x4 = self.down_4.forward_skip(x3)
         u4 = self.upcat_4.forward_act(x4, s3)
@@ -349,6 +359,23 @@ class BasicUNet(_Mi355Module):
     def forward(self, x):
         z = self.forward_act(self._to_act(x, round_up(self.in_channels, 16)))
         return Fn.UnpackFn.apply(z, self.out_channels)
+
+
+def backward_stages(net: nn.Module, modality):
+    """(late, early) parameter lists of a Generator / Discriminator for the two backward stages cut at
+    ``Fn.StageBoundary`` (the unused modality heads are in neither list: src/model.py:29-34, 74-78)."""
+    if isinstance(net, Generator):
+        unet = net.blocks["unet"]
+        early_mods = [net.blocks[modality], unet.conv_0, unet.down_1, unet.down_2]
+        late_mods = [unet.down_3, unet.down_4, unet.upcat_4, unet.upcat_3, unet.upcat_2, unet.upcat_1, unet.final_conv]
+    elif isinstance(net, Discriminator):
+        early_mods = [net.d1[modality], net.d2]
+        late_mods = [net.d3, net.d4, net.d5, net.final]
+    else:
+        raise TypeError("backward_stages: Generator or Discriminator expected")
+    late = [p for m in reversed(late_mods) for p in reversed(list(m.parameters()))]
+    early = [p for m in reversed(early_mods) for p in reversed(list(m.parameters()))]
+    return late, early
 
 
 class Generator(_Mi355Module):

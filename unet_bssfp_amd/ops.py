@@ -310,6 +310,15 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def colsum_into(x: torch.Tensor, out: torch.Tensor, accumulate: bool):
+    """Per-channel sum over all rows written into (or added to) the first out.numel() channels of `out` (f32)."""
+    require_cuda(x, out)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() <= x.shape[4]
+    part, bpg = channel_stats(x, 1)
+    _lib.check(_lib.load().mi355_colsum_finalize_into(part.data_ptr(), bpg, x.shape[4], out.data_ptr(), out.numel(),
+                                                      1 if accumulate else 0, _stream()), "colsum_into")
+
+
 def _normact_desc(z, groups, mean, rstd, gamma, beta, slope, drop_p, seed, seed_t=None):
     d = _lib.NormActDesc()
     n, dd, h, w, c = z.shape
@@ -354,9 +363,11 @@ def normact_fwd(z, groups, mean, rstd, gamma, beta, slope, drop_p=0.0, seed=0, o
 
 
 def normact_bwd(z, da, groups, mean, rstd, gamma, beta, slope, drop_p, seed, batch_stats, want_affine_grads,
-                s2d=False, seed_t=None):
+                s2d=False, seed_t=None, affine_into=None, accumulate=False):
     """Returns (dz, dgamma, dbeta).  dgamma/dbeta are f32 [C] (None if there is no norm).
-    s2d=True: `da` is a gradient in space-to-depth layout (the forward wrote S(a))."""
+    s2d=True: `da` is a gradient in space-to-depth layout (the forward wrote S(a)).
+    affine_into=(dgamma, dbeta): write (accumulate=True: add) the affine gradients into these caller-owned f32
+    vectors of the real channel count instead of returning new ones (then None, None are returned for them)."""
     require_cuda(z, da)
     lib = _lib.load()
     n, dd, h, w, c = z.shape
@@ -378,11 +389,19 @@ def normact_bwd(z, da, groups, mean, rstd, gamma, beta, slope, drop_p, seed, bat
         d.part, d.blocks_per_group = part.data_ptr(), bpg
         _lib.check(lib.mi355_normact_bwd_reduce(C.byref(d), _stream()), "normact_bwd_reduce")
         sums = torch.empty((groups, 2, c), dtype=torch.float32, device=z.device)
-        dgamma = torch.empty((c,), dtype=torch.float32, device=z.device)
-        dbeta = torch.empty((c,), dtype=torch.float32, device=z.device)
-        _lib.check(lib.mi355_normact_bwd_finalize(part.data_ptr(), bpg, groups, c, sums.data_ptr(),
-                                                  dgamma.data_ptr(), dbeta.data_ptr(), _stream()),
-                   "normact_bwd_finalize")
+        if affine_into is not None:
+            g_into, b_into = affine_into
+            require_cuda(g_into, b_into)
+            assert g_into.dtype == b_into.dtype == torch.float32 and g_into.numel() == b_into.numel() <= c
+            _lib.check(lib.mi355_normact_bwd_finalize_into(part.data_ptr(), bpg, groups, c, sums.data_ptr(),
+                                                           g_into.data_ptr(), b_into.data_ptr(), g_into.numel(),
+                                                           1 if accumulate else 0, _stream()), "normact_bwd_finalize")
+        else:
+            dgamma = torch.empty((c,), dtype=torch.float32, device=z.device)
+            dbeta = torch.empty((c,), dtype=torch.float32, device=z.device)
+            _lib.check(lib.mi355_normact_bwd_finalize(part.data_ptr(), bpg, groups, c, sums.data_ptr(),
+                                                      dgamma.data_ptr(), dbeta.data_ptr(), _stream()),
+                       "normact_bwd_finalize")
         d.sums = sums.data_ptr()
         keep += [part, sums]
     _lib.check(lib.mi355_normact_bwd_apply(C.byref(d), _stream()), "normact_bwd_apply")
