@@ -96,7 +96,7 @@ class Probe:
         if not self.enabled:
             return None
         cin, cout = real if real is not None else (d.c0 + d.c1, d.cstore)
-        return self._bracket(self.conv, plan_id, 2.0 * cin * cout * (d.ks ** 3) * d.n * d.do_ * d.ho * d.wo)
+        return self._bracket(self.conv, (plan_id, int(d.dtype)), 2.0 * cin * cout * (d.ks ** 3) * d.n * d.do_ * d.ho * d.wo)
 
     def norm_probe(self, kind, c_real, rows, elem_bytes):
         if not self.enabled:
@@ -109,9 +109,14 @@ class Probe:
         ms = sum(a.elapsed_time(b) for a, b in ent[0])
         return dict(launches=len(ent[0]), total_ms=ms, avg_ms=ms / max(1, len(ent[0])), work=ent[1])
 
-    def dominant_conv(self):
+    def dominant_conv(self, only_dtype=None):
+        """(plan id, operand dtype code), summary of the convolution kernel family with the largest summed duration;
+        ``only_dtype``: among the launches with that operand type (``--dtype fp8``: the e4m3 kernel is the one the
+        configuration is about; the layers it does not take run on bf16 operands and are listed by share)."""
         best = None
         for pid, ent in self.conv.items():
+            if only_dtype is not None and pid[1] != only_dtype:
+                continue
             s = self._sum(ent)
             if best is None or s["total_ms"] > best[1]["total_ms"]:
                 best = (pid, s)
@@ -379,10 +384,10 @@ def main():
             "ms_per_step_first_half": first_ms, "ms_per_step_last_half": last_ms,
             "nondefault": nondefault or None,
         }
-        dom = probe.dominant_conv()
+        dom = probe.dominant_conv(3 if a.dtype == "fp8" else None)
         if dom:
-            pid, s = dom
-            name = PLAN_NAMES.get(pid, f"conv plan {pid}")
+            (pid, dcode), s = dom
+            name = PLAN_NAMES.get(pid, f"conv plan {pid}") + {3: "<e4m3>", 1: "", 2: "", 0: ""}.get(dcode, "")
             ach = s["work"] / (s["total_ms"] * 1e-3) / 1e12
             traffic, tinfo = profiled_traffic(name, a.dtype, a.size, a.workload, a.batch)
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",

@@ -36,6 +36,7 @@ extern "C" {
 #define MI355_DT_F32 0
 #define MI355_DT_BF16 1
 #define MI355_DT_F64 2   /* mi355_dti_scalar_maps only */
+#define MI355_DT_FP8 3   /* OCP e4m3: operands of the fp8 convolution path only (mi355_conv_fwd, mi355_weight_pack) */
 
 #define MI355_OK 0
 #define MI355_ERR_ARG (-1)
@@ -99,6 +100,8 @@ typedef struct mi355_wpack_desc {
    * blk*s2d_cp + c (cin = real channels per block, cinp = 8*s2d_cp), 2 = the GEMM cout index is;
    * the block's parity bits (bd,bh,bw) are added to the source tap coordinates. 0 = off. */
   int32_t s2d_mode, s2d_cp;
+  /* dtype MI355_DT_FP8: device f32[1] holding max |src| (mi355_amax_f32); packed value = e4m3(w * 224 / amax) */
+  const float* q_amax;
 } mi355_wpack_desc;
 int mi355_weight_pack(const mi355_wpack_desc* d, void* stream);
 /* n packings in ceil(n/16) launches (descriptors travel by value; all must share one dtype) */
@@ -139,6 +142,10 @@ typedef struct mi355_conv_desc {
    * 0 = off.  Weights: mi355_weight_pack with s2d_mode 2, s2d_cp = cls_cout. */
   int32_t cls_cout;
   int32_t nbias;                  /* length of bias (0: coutp, for callers that pad it) */
+  /* dtype MI355_DT_FP8 (BASELINE.json configs[4]: 3x3x3 stride-1 layers with 32 input channels at full resolution):
+   * x0 is e4m3 of x * 224 / amax_x (mi355_cast_fp8: one byte per channel, ld0 in bytes), wp is packed with
+   * MI355_DT_FP8, y / statistics are bf16 / f32 as in the bf16 mode.  Both amax pointers: device f32[1]. */
+  const float* q_amax_x; const float* q_amax_w;
 } mi355_conv_desc;
 int mi355_conv_fwd(const mi355_conv_desc* d, void* stream);
 int64_t mi355_conv_workspace_bytes(const mi355_conv_desc* d);
@@ -358,6 +365,20 @@ int mi355_aug_noise(const float* x, float* out, int64_t count, float mean, float
 
 /* layout probe used by the tests: writes lane -> (row, col) maps of the MFMA accumulators */
 int mi355_mfma_selftest(float* out_f32_1024, float* out_bf16_1024, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * fp8 operand preparation (per-tensor scaling, OCP e4m3): amax = max |x| over a tensor (the call zeroes *amax first),
+ * cast = e4m3(x * 224 / amax) (scale 1 if amax == 0), saturating at +-448.
+ *   mi355_amax_f32 : contiguous f32 array (weights)
+ *   mi355_amax_act : NDHWC activation rows (bf16 or f32), c channels of ld
+ *   mi355_cast_fp8 : activation rows -> one byte per channel, row stride ld_dst bytes
+ * mi355_fp8_selftest: D = A B on v_mfma_scale_f32_32x32x64_f8f6f4 with exact small-integer e4m3 operands.
+ * ---------------------------------------------------------------------------------------- */
+int mi355_amax_f32(const float* x, int64_t n, float* amax, void* stream);
+int mi355_amax_act(const void* x, int32_t ld, int32_t c, int64_t rows, int32_t dtype, float* amax, void* stream);
+int mi355_cast_fp8(const void* src, int32_t ld_src, int32_t c, int64_t rows, int32_t src_dtype, const float* amax,
+                   void* dst, int32_t ld_dst, void* stream);
+int mi355_fp8_selftest(float* out_1024, void* stream);
 
 #ifdef __cplusplus
 }

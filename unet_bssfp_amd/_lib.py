@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmi355_unet.so")   # the one shipped build; no
 
 DT_F32 = 0
 DT_BF16 = 1
+DT_FP8 = 3
 
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
 
@@ -20,7 +21,8 @@ _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_v
 class WpackDesc(C.Structure):
     _fields_ = [("src", _vp), ("dst", _vp), ("cout", _i32), ("cin", _i32), ("coutp", _i32), ("cinp", _i32),
                 ("ks", _i32), ("s_co", _i64), ("s_ci", _i64), ("s_k", _i64 * 3),
-                ("tbase", _i32 * 3), ("tstep", _i32 * 3), ("dtype", _i32), ("s2d_mode", _i32), ("s2d_cp", _i32)]
+                ("tbase", _i32 * 3), ("tstep", _i32 * 3), ("dtype", _i32), ("s2d_mode", _i32), ("s2d_cp", _i32),
+                ("q_amax", _vp)]
 
 
 class ConvDesc(C.Structure):
@@ -30,7 +32,8 @@ class ConvDesc(C.Structure):
                 ("pad", _i32 * 3), ("wp", _vp), ("coutp", _i32), ("bias", _vp),
                 ("y", _vp), ("ldy", _i32), ("cstore", _i32), ("dy", _i32), ("hy", _i32), ("wy", _i32),
                 ("os", _i32), ("ooff", _i32 * 3), ("stats_part", _vp), ("dtype", _i32),
-                ("workspace", _vp), ("workspace_bytes", _i64), ("cls_cout", _i32), ("nbias", _i32)]
+                ("workspace", _vp), ("workspace_bytes", _i64), ("cls_cout", _i32), ("nbias", _i32),
+                ("q_amax_x", _vp), ("q_amax_w", _vp)]
 
 
 class WgradDesc(C.Structure):
@@ -103,6 +106,10 @@ _SIGNATURES = {
     "mi355_aug_gamma": (C.c_int, [_vp, _vp, _i64, _f32, _vp]),
     "mi355_aug_noise": (C.c_int, [_vp, _vp, _i64, _f32, _f32, C.c_uint64, _vp]),
     "mi355_mfma_selftest": (C.c_int, [_vp, _vp, _vp]),
+    "mi355_amax_f32": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "mi355_amax_act": (C.c_int, [_vp, _i32, _i32, _i64, _i32, _vp, _vp]),
+    "mi355_cast_fp8": (C.c_int, [_vp, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _vp]),
+    "mi355_fp8_selftest": (C.c_int, [_vp, _vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -11,6 +11,18 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // storage type of bf16 activations / packed weights
 struct bf16_t { uint16_t v; };
+// OCP e4m3 operand of the fp8 convolution path (per-tensor scaled: value * 224 / amax)
+struct fp8_t { uint8_t v; };
+__device__ __forceinline__ float fp8_clamp(float f) { return fminf(fmaxf(f, -448.f), 448.f); }
+// two floats -> two e4m3 bytes in the low (hi = false) or high half of `old`
+__device__ __forceinline__ uint32_t cvt_pk_fp8(float a, float b, uint32_t old, bool hi) {
+  return hi ? (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(fp8_clamp(a), fp8_clamp(b), (int)old, true)
+            : (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(fp8_clamp(a), fp8_clamp(b), (int)old, false);
+}
+__device__ __forceinline__ float fp8_scale_of(const float* amax) {
+  const float m = amax ? amax[0] : 0.f;
+  return m > 0.f ? 224.f / m : 1.f;
+}
 
 // ---- error plumbing (thread-local message, no exceptions across the ABI) ----
 void mi355_set_error(const char* fmt, ...);
@@ -44,6 +56,11 @@ template <> struct Elem<bf16_t> {
   static constexpr int kPer16B = 8;
   static __device__ __forceinline__ float load(const bf16_t* p) { return bf16_bits_to_f32(p->v); }
   static __device__ __forceinline__ void store(bf16_t* p, float v) { p->v = f32_to_bf16_bits(v); }
+};
+template <> struct Elem<fp8_t> {           // stores only (weight packing): the caller has applied the tensor scale
+  static constexpr int kDtype = MI355_DT_FP8;
+  static constexpr int kPer16B = 16;
+  static __device__ __forceinline__ void store(fp8_t* p, float v) { p->v = (uint8_t)(cvt_pk_fp8(v, 0.f, 0u, false) & 0xffu); }
 };
 
 // 16 bytes of T unpacked to floats (4 for f32, 8 for bf16)

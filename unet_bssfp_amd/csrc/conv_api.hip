@@ -44,11 +44,15 @@ constexpr int forced_shape() { return -1; }
 
 int make_plan(const mi355_conv_desc* d, Plan* p) {
   MI355_REQUIRE(d && d->x0 && d->wp && d->y, "conv: null pointer");
-  MI355_REQUIRE(d->dtype == MI355_DT_F32 || d->dtype == MI355_DT_BF16, "conv: bad dtype %d", d->dtype);
+  MI355_REQUIRE(d->dtype == MI355_DT_F32 || d->dtype == MI355_DT_BF16 || d->dtype == MI355_DT_FP8, "conv: bad dtype %d", d->dtype);
+  MI355_REQUIRE(d->dtype != MI355_DT_FP8 || (d->q_amax_x && d->q_amax_w), "conv: fp8 operands need q_amax_x / q_amax_w");
   MI355_REQUIRE(d->c0 > 0 && d->c0 % 16 == 0 && d->c1 >= 0 && d->c1 % 16 == 0, "conv: channels must be multiples of 16 (c0=%d c1=%d)", d->c0, d->c1);
   MI355_REQUIRE(d->c1 == 0 || d->x1, "conv: c1 > 0 without x1");
   MI355_REQUIRE(d->ld0 >= d->c0 && (d->c1 == 0 || d->ld1 >= d->c1), "conv: ld < channels");
-  MI355_REQUIRE(d->ld0 % (d->dtype == MI355_DT_F32 ? 4 : 8) == 0 && (d->c1 == 0 || d->ld1 % (d->dtype == MI355_DT_F32 ? 4 : 8) == 0), "conv: ld must keep rows 16-byte aligned");
+  {
+    const int epv = d->dtype == MI355_DT_F32 ? 4 : (d->dtype == MI355_DT_FP8 ? 16 : 8);
+    MI355_REQUIRE(d->ld0 % epv == 0 && (d->c1 == 0 || d->ld1 % epv == 0), "conv: ld must keep rows 16-byte aligned");
+  }
   MI355_REQUIRE(d->coutp > 0 && d->coutp % 32 == 0, "conv: coutp %% 32 != 0");
   MI355_REQUIRE(d->cstore > 0 && d->cstore <= d->coutp && d->ldy >= d->cstore, "conv: bad cstore/ldy");
   MI355_REQUIRE(d->ks >= 1 && d->ks <= 4 && d->stride >= 1 && d->stride <= 2, "conv: unsupported ks=%d stride=%d", d->ks, d->stride);
@@ -75,12 +79,13 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
              (d->coutp / (32 * ct));
     };
     if (p->shape == 0) {
-      if (d->dtype == MI355_DT_BF16 && d->ks == 3) {
+      if ((d->dtype == MI355_DT_BF16 || d->dtype == MI355_DT_FP8) && d->ks == 3) {
         // wide bf16 3x3x3 layers: the row-reuse + LDS-DMA kernel (shape 9) when its 4x4x32 tiles fill the chip,
         // else 8-wave 4x4x32 tiles (shape 6) / the plain 2x4x32 tile.
         const int f = forced_shape();
         const long long nv = (long long)d->n * d->di * d->hi * d->wi;
-        const bool ru_ok = nv * d->ld0 * 2 < (1ll << 31) && nv * (d->c1 ? d->ld1 : 0) * 2 < (1ll << 31);   // 32-bit byte offsets
+        const bool ru_ok = nv * d->ld0 * 2 < (1ll << 31) && nv * (d->c1 ? d->ld1 : 0) * 2 < (1ll << 31) &&
+                           (long long)d->n * d->dy * d->hy * d->wy * d->ldy * 2 < (1ll << 31);                       // 32-bit byte offsets
         const bool big = count(6, p->ct) >= 1024;
         const long long c9 = count(9, p->ct);
         int pick = (p->ct == 1 ? c9 >= 1024 : c9 >= 512) ? 9 : (big ? 6 : 0);
@@ -107,7 +112,7 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
             if (best < 0 || cost < best) { best = cost; best_len = len; }
           }
           const int segs = ceil_div(d->do_, best_len);
-          if (fp * segs >= 128 || f == 10) {
+          if (fp * segs >= 128 || f == 10 || d->dtype == MI355_DT_FP8) {
             pick = 10;
             p->seg_len = best_len;
             p->nseg = segs;
@@ -149,6 +154,8 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
     p->tiles_d = p->tiles_h = p->tiles_w = 0;
     p->shape = 0;
   }
+  MI355_REQUIRE(d->dtype != MI355_DT_FP8 || (p->halo && p->shape == 10),
+                "conv: the fp8 path covers 3x3x3 stride-1 layers with 32 input channels in one source and a plain output grid");
   MI355_REQUIRE(p->tiles < (1ll << 31), "conv: too many tiles");
   p->ksplit = 1; p->rpb = 0;
   p->stat_rows = p->tiles; p->stat_rows_per_sample = p->tiles_per_sample;
@@ -238,10 +245,14 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
         }
       } else if (p.shape == 10) {
         if constexpr (sizeof(T) == 2) {
-          static const int once = [] { return (int)hipFuncSetAttribute((const void*)conv_march_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMarchLds); }();
+          static const int once = [] {
+            (void)hipFuncSetAttribute((const void*)conv_march_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MarchCfg<false>::LDS);
+            return (int)hipFuncSetAttribute((const void*)conv_march_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MarchCfg<true>::LDS);
+          }();
           (void)once;
-          MarchArgs m{p.seg_len, p.nseg, p.tiles_h, p.tiles_w};
-          conv_march_kernel<<<grid, block, kMarchLds, st>>>(a, m);
+          MarchArgs m{p.seg_len, p.nseg, p.tiles_h, p.tiles_w, d->q_amax_x, d->q_amax_w};
+          if (d->dtype == MI355_DT_FP8) conv_march_kernel<true><<<grid, block, MarchCfg<true>::LDS, st>>>(a, m);
+          else conv_march_kernel<false><<<grid, block, MarchCfg<false>::LDS, st>>>(a, m);
         }
       } else if (p.shape == 9) {
         if constexpr (sizeof(T) == 2) {

@@ -1,61 +1,71 @@
-// conv_march_kernel: bf16 3x3x3 stride-1 convolution of the full-resolution layers with <= 32 input channels
-// (U-Net conv_0.*, upcat_1.conv_1 and their data gradients: 32 -> 32 / 96 output channels at 128^3 / 160^3).
+// conv_march_kernel<F8>: 3x3x3 stride-1 convolution of the full-resolution layers with <= 32 input channels
+// (U-Net conv_0.*, upcat_1.conv_1 and their data gradients: 32 -> 32 / 96 output channels at 128^3 / 160^3),
+// bf16 operands (F8 = false) or OCP e4m3 operands on the block-scaled MFMA (F8 = true, BASELINE.json configs[4]).
 //
 // Why another structure (profiles/r01_pmc_conv_ru.txt): conv_ru_kernel stages the 6x6x34 halo of one 16-channel chunk
 // per pass -- 2.39x the tile's own voxels, half of every 128-B line per pass -- and the L2 keeps neither the halo
 // overlap nor the line until the second chunk pass: 4.0x the input tensor crossed the fabric, so the kernel ran at
 // the memory system's pace (691 MB in 155 us), not the MFMA's.  Here a workgroup owns a 16 (h) x 32 (w) footprint and
 // MARCHES along d:
-//   * each input plane of the footprint (18 x 34 voxels, ALL 32 channels: whole 64-B voxel rows) is brought into LDS
-//     exactly once per workgroup with `buffer_load_dwordx4 ... lds` (1 KB = 16 voxels x 64 B per instruction), while
-//     the previous plane is being consumed (two plane buffers, one barrier per plane): halo re-reads 1.20x in (h, w)
-//     and (L + 2) / L along d for a segment of L planes -- 1.35x instead of 4.0x;
+//   * each input plane of the footprint (18 x 34 voxels, ALL 32 channels: whole voxel rows) is brought into LDS exactly
+//     once per workgroup with `buffer_load_dwordx4 ... lds` (1 KB per instruction), while the previous plane is being
+//     consumed (two plane buffers, one barrier per plane): halo re-reads 1.20x in (h, w) and (L + 2) / L along d for a
+//     segment of L planes -- 1.35x instead of 4.0x;
 //   * input-stationary: an input plane feeds the three output planes d-1, d, d+1 (kd = 2, 1, 0), whose accumulators
 //     (3 planes x 4 rows x 32 voxels x 32 channels per wave = 192 registers) stay in registers; a plane is finished,
 //     converted and stored when its kd = 2 contribution is in; the register sets rotate by unrolling the march by 3;
-//   * the packed weights of the workgroup's 32 output channels (2 chunks x 27 taps x 1 KB = 54 KB) are loaded into
-//     LDS ONCE; a weight fragment read from LDS feeds 4 rows, an activation fragment 3 taps (kh): 0.75 ds_read_b128
-//     per MFMA, no per-wave weight traffic through L1 at all;
-//   * 4 waves = one per SIMD (launch bound 1: the 512-entry register file is this wave's), 140 KB of LDS: one
-//     workgroup per CU, and the segment length is chosen so that the grid is a whole number of 256-workgroup rounds;
+//   * the packed weights of the workgroup's 32 output channels (54 KB bf16 / 30 KB fp8) are loaded into LDS ONCE; a
+//     weight fragment read from LDS feeds 4 rows;
+//   * the weights are the MFMA's A operand (rows = output channels), the activations its B operand (columns = voxels),
+//     and the weight rows are permuted so that a lane ends up with 16 CONTIGUOUS channels of one voxel: the epilogue is
+//     two 16-byte stores per lane and row, no transposition;
+//   * 4 waves = one per SIMD (launch bound 1: the 512-entry register file is this wave's), one workgroup per CU; the
+//     segment length is chosen so that the grid is a whole number of 256-workgroup rounds (conv_api.hip);
 //   * the per-channel statistics of the whole segment are accumulated in registers and written once.
-// LDS plane image: voxel-major, 64 B per voxel (4 octets of 8 channels), octet o of voxel v = (row, col) of the 18 x 34
-// halo plane in 16-B slot 4 v + (o ^ ((col >> 2) & 3)): the DMA writes lane-linear, so the swizzle sits on the per-lane
-// SOURCE address, and a fragment read (32 consecutive voxels of a row, one octet) touches 16 distinct slots mod 16 in
-// every ds_read_b128 lane group.  The swizzle depends on the column only, so the 6 halo rows a wave reads are one
-// address register plus immediate offsets.
+//
+// bf16: per (kd) block 2 chunks x 3 kw "groups" of {3 weight fragments (kh), 6 activation fragments (halo rows), 12
+// v_mfma_f32_32x32x16_bf16}: an activation fragment feeds the 3 kh taps (row reuse), 0.75 ds_read_b128 per MFMA.
+// fp8 : K = 64 per v_mfma_scale_f32_32x32x64_f8f6f4 = TWO taps x 32 channels (lane half h holds tap 2 pair + h), so the 9
+// (kh, kw) taps of a kd block are 5 pairs (the 10th tap has zero weights): per pair one weight fragment (32 B per lane)
+// and, per output row, one activation fragment whose lane halves read two different halo positions; 15 MFMAs of 64
+// cycles per row and plane instead of 54 of 32.  Block scales are 1 (E8M0 127); the per-TENSOR scales of the operands
+// (x8 = x * 224 / amax(x), likewise the weights) are divided out in the epilogue.
+//
+// LDS plane image: voxel-major; 16-B slot (q ^ swz(col)) of voxel (row, col) holds channel piece q, swz = (col >> 2) & 3
+// for the 4 pieces of a 64-B bf16 voxel, (col >> 3) & 1 for the 2 pieces of a 32-B fp8 voxel: the DMA writes lane-linear,
+// so the swizzle sits on the per-lane SOURCE address, and a fragment read (32 consecutive voxels of a row, one piece)
+// touches 16 distinct slots mod 16 in every ds_read_b128 lane group.  The swizzle depends on the column only: the
+// halo rows a wave reads are one address register plus immediate offsets.
 #pragma once
 #include "conv_common.h"
-#ifndef MARCH_SGB_VMEM
-#define MARCH_SGB_VMEM 0
-#endif
-#ifndef MARCH_SGB_VALU
-#define MARCH_SGB_VALU 0
-#endif
-#ifndef MARCH_EPI_AT
-#define MARCH_EPI_AT 5
-#endif
-#ifndef MARCH_SGB
-#define MARCH_SGB 1
-#endif
 
 constexpr int kMarchFH = 16, kMarchFW = 32, kMarchHR = kMarchFH + 2, kMarchHC = kMarchFW + 2;
 constexpr int kMarchVox = kMarchHR * kMarchHC;                       // 612 halo voxels per plane
-constexpr int kMarchBlocks = 40;                                     // 1-KB DMA instructions per plane (16 voxels x 64 B; 39 needed,
-                                                                     // 40 = 10 per wave: no branch inside a march step)
-constexpr int kMarchPlane = kMarchBlocks * 1024;                     // 40 KB
-constexpr int kMarchWeights = 2 * 27 * 1024;                         // 54 KB
-constexpr int kMarchLds = 2 * kMarchPlane + kMarchWeights + 4096 + 10 * 1024;   // + statistics scratch, bias; DMA offset table
 
-struct MarchArgs { int seg_len, nseg, tiles_h, tiles_w; };
+template <bool F8> struct MarchCfg {
+  static constexpr int VB = F8 ? 32 : 64;                            // bytes per voxel (32 channels)
+  static constexpr int PIECES = VB / 16;                             // 16-B pieces per voxel
+  static constexpr int BLOCKS = F8 ? 20 : 40;                        // 1-KB DMA instructions per plane: a multiple of 4, so that
+                                                                     // every wave issues the same number (no branch in a step)
+  static constexpr int PLANE = BLOCKS * 1024;
+  static constexpr int NWI = F8 ? 30 : 54;                           // 1-KB weight blocks
+  static constexpr int WBYTES = NWI * 1024;
+  static constexpr int LDS = 2 * PLANE + WBYTES + 4096 + (BLOCKS / 4) * 1024;   // + statistics scratch, bias; DMA offset table
+};
 
+struct MarchArgs { int seg_len, nseg, tiles_h, tiles_w; const float* amax_x; const float* amax_w; };
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+template <bool F8>
 __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, const MarchArgs m) {
-  using T = bf16_t;
-  constexpr int HC = kMarchHC, NI = (kMarchBlocks + 3) / 4, NW = (54 + 3) / 4;
+  using T = bf16_t;                                                  // output element
+  using Cfg = MarchCfg<F8>;
+  constexpr int HC = kMarchHC, NI = Cfg::BLOCKS / 4, NW = (Cfg::NWI + 3) / 4, VB = Cfg::VB, XB = F8 ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
-  char* const wl = smem + 2 * kMarchPlane;
-  char* const patch = wl + kMarchWeights;
+  char* const wl = smem + 2 * Cfg::PLANE;
+  char* const patch = wl + Cfg::WBYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
@@ -76,72 +86,110 @@ __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, co
   const int d0 = seg * m.seg_len, d1 = min(a.do_, d0 + m.seg_len);     // output planes [d0, d1)
   const int h0 = th_i * kMarchFH, w0 = tw_i * kMarchFW;
 
-  // ---- DMA set-up: instruction id = i * 4 + wave covers halo voxels id * 16 .. + 15, lane = (voxel, slot).  The ten
-  //      per-lane source offsets live in LDS (one ds_read_b32 each per plane): as registers they were the ones hipcc
-  //      spilled to scratch, and a scratch reload at the top of every step drags a vmcnt(0) in front of the DMA issue.
+  // ---- DMA set-up: instruction id = i * 4 + wave covers 64 / PIECES halo voxels, lane = (voxel, slot).  The per-lane
+  //      source offsets live in LDS (one ds_read_b32 each per plane): as registers they were the ones hipcc spilled to
+  //      scratch, and a scratch reload at the top of every step drags a vmcnt(0) in front of the DMA issue.
   int* const vtab = reinterpret_cast<int*>(patch + 4096) + tid;
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const int id = i * 4 + wave, v = id * 16 + (lane >> 2);
+    const int id = i * 4 + wave, v = id * (64 / Cfg::PIECES) + lane / Cfg::PIECES;
     const int hy = v / HC, hx = v - hy * HC;
-    const int o = (lane & 3) ^ ((hx >> 2) & 3);                      // the octet this slot holds
+    const int swz = F8 ? ((hx >> 3) & 1) : ((hx >> 2) & 3);
+    const int q = (lane % Cfg::PIECES) ^ swz;                        // the channel piece this slot holds
     const int gh = h0 - a.ph + hy, gw = w0 - a.pw + hx;
-    const bool ok = id < kMarchBlocks && v < kMarchVox && gh >= 0 && gh < a.hi && gw >= 0 && gw < a.wi;
-    vtab[i * 256] = ok ? ((gh * a.wi + gw) * a.ld0 + o * 8) * 2 : (int)0x80000000;
+    const bool ok = v < kMarchVox && gh >= 0 && gh < a.hi && gw >= 0 && gw < a.wi;
+    vtab[i * 256] = ok ? ((gh * a.wi + gw) * a.ld0 * XB + q * 16) : (int)0x80000000;
   }
   const long long nvox = (long long)a.n * a.di * a.hi * a.wi;
-  const auto rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x0, 0, (int)(((nvox - 1) * a.ld0 + a.c0) * 2), 0x00020000);
-  const auto rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, 54 * a.coutp * 32, 0x00020000);
-  const int plane_stride = a.hi * a.wi * a.ld0 * 2;                   // bytes per input plane
-  auto load_plane = [&](int p) __attribute__((always_inline)) {                                      // p: input plane index (may be outside [0, D): zeros)
+  const auto rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x0, 0, (int)(((nvox - 1) * a.ld0 + a.c0) * XB), 0x00020000);
+  const auto rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, 54 * a.coutp * 16 * XB, 0x00020000);
+  const int plane_stride = a.hi * a.wi * a.ld0 * XB;                  // bytes per input plane
+  auto load_plane = [&](int p) __attribute__((always_inline)) {       // p: input plane index (outside [0, D): zeros)
     const bool pin = p >= 0 && p < a.di;
     const int soff = pin ? (tn * a.di + p) * plane_stride : 0;
-    char* dst = smem + (p & 1) * kMarchPlane + wave * 1024;
+    const int kill = pin ? 0 : (int)0x80000000;                       // OR-ed in: out of range -> the DMA writes zeros (no branch)
+    char* dst = smem + (p & 1) * Cfg::PLANE + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(dst + i * 4096), 16, pin ? vtab[i * 256] : (int)0x80000000, soff, 0, 0);
+    for (int i = 0; i < NI; ++i) {
+      // (bf16: the select form, which hipcc turns into short branches, keeps the table reads next to their DMA -- hoisted
+      //  together as in the OR form they cost 10 registers this variant does not have)
+      const int voff = F8 ? (vtab[i * 256] | kill) : (pin ? vtab[i * 256] : (int)0x80000000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(dst + i * 4096), 16, voff, soff, 0, 0);
+    }
   };
-  // ---- weights of this workgroup's 32 output channels: [chunk][tap] blocks of [lane half][row] x 16 B.  The weights are
-  //      the MFMA's A operand (rows = output channels, columns = voxels), so that a lane ends up with 16 channels of ONE
-  //      voxel; row rho of the fragment holds output channel pi(rho) = 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3),
-  //      which makes the 16 accumulator registers of lane half h' the CONTIGUOUS channels 16 h' .. 16 h' + 15: the
-  //      epilogue is two 16-byte stores per lane, no transposition.  (The permutation costs nothing: it sits on the
-  //      per-lane source address of the LDS-DMA.)
+  // ---- weights of this workgroup's 32 output channels, one 1-KB block = [lane half][row] x 16 B per fragment piece.  Row
+  //      rho of a fragment holds output channel pi(rho) = 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3), which makes
+  //      the 16 accumulator registers of lane half h' the contiguous channels 16 h' .. 16 h' + 15.  (The permutation costs
+  //      nothing: it sits on the per-lane source address of the LDS-DMA.)
   const int wrow = 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
 #pragma unroll
   for (int i = 0; i < NW; ++i) {
     const int j = i * 4 + wave;
-    if (j < 54)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(wl + j * 1024), 16, ((j * a.coutp + co_base + wrow) * 2 + h) * 16, 0, 0, 0);
+    if (j < Cfg::NWI) {
+      int src;
+      if constexpr (F8) {      // block j = (kd * 5 + pair) * 2 + piece: lane half h holds tap 2 pair + h of the kd plane (tap 9: zeros)
+        const int piece = j & 1, pr = (j >> 1) % 5, kd = (j >> 1) / 5, tp = 2 * pr + h;
+        src = tp < 9 ? ((piece * 27 + kd * 9 + tp) * a.coutp + co_base + wrow) * 16 : (int)0x80000000;
+      } else {                 // block j = chunk * 27 + tap: lane half h holds channels 8 h .. 8 h + 7 of the chunk
+        src = ((j * a.coutp + co_base + wrow) * 2 + h) * 16;
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(wl + j * 1024), 16, src, 0, 0, 0);
+    }
   }
   load_plane(d0 - 1);
 
-  // ---- per-lane LDS offsets of the activation fragments: halo row 4 wave + hy (immediate: hy * 34 * 64 B), voxels
-  //      kw + r, octet 2 c + h
-  int aoff[3][2];
+  // ---- per-lane LDS offsets of the activation fragments (halo row = 4 wave + immediate)
+  //      bf16: [kw][chunk] -> voxels kw + r, piece 2 chunk + h;  fp8: [pair][piece] -> lane half h reads tap 2 pair + h
+  int aoff[F8 ? 5 : 3][2];
+  if constexpr (F8) {
 #pragma unroll
-  for (int kw = 0; kw < 3; ++kw) {
-    const int col = kw + r, v = 4 * wave * HC + col, s = (col >> 2) & 3;
+    for (int pr = 0; pr < 5; ++pr) {
+      const int tp = min(2 * pr + h, 8), kh = tp / 3, kw = tp - kh * 3;      // (pair 4, h = 1: any valid address, its weights are zero)
+      const int col = kw + r, v = (4 * wave + kh) * HC + col, s = (col >> 3) & 1;
+      aoff[pr][0] = (2 * v + s) * 16;
+      aoff[pr][1] = (2 * v + (1 ^ s)) * 16;
+    }
+  } else {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) aoff[kw][c] = (4 * v + ((2 * c + h) ^ s)) * 16;
+    for (int kw = 0; kw < 3; ++kw) {
+      const int col = kw + r, v = 4 * wave * HC + col, s = (col >> 2) & 3;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) aoff[kw][c] = (4 * v + ((2 * c + h) ^ s)) * 16;
+    }
   }
   const char* const wlane = wl + lane * 16;
 
   // this lane: voxel w0 + r of a row, output channels co_base + 16 h .. + 15
   const int cch = co_base + 16 * h;
-  // the bias is the accumulators' initial value (one LDS read of 16 floats where an output plane starts); the
-  // statistics are taken of z = acc and turned into those of (z - bias) once, at the end
+  // fp8: the operands are x * sx and w * sw with per-tensor s = 224 / amax; the accumulators are divided by sx * sw
+  float deq = 1.f;
+  if constexpr (F8) {
+    const float ax = m.amax_x[0], aw = m.amax_w[0];
+    deq = (ax > 0.f ? ax * (1.f / 224.f) : 1.f) * (aw > 0.f ? aw * (1.f / 224.f) : 1.f);
+  }
+  // the bias (in accumulator units) is the accumulators' initial value (one LDS read of 16 floats where an output plane
+  // starts); the statistics are taken of z = acc * deq and turned into those of (z - bias) once, at the end
   float s1[16], s2[16];
-  float* const blds = reinterpret_cast<float*>(patch) + 512;          // [32] bias of this workgroup's channels
-  if (tid < 32) blds[tid] = (a.bias && co_base + tid < a.nbias) ? a.bias[co_base + tid] : 0.f;
+  float* const blds = reinterpret_cast<float*>(patch) + 512;          // [32] bias / deq of this workgroup's channels
+  if (tid < 32) blds[tid] = ((a.bias && co_base + tid < a.nbias) ? a.bias[co_base + tid] : 0.f) / deq;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
   int nstat = 0;                                                      // voxels this lane has added to its sums
   const bool vox_ok = w0 + r < a.wo;
   const bool st0 = vox_ok && cch + 8 <= a.cstore, st1 = vox_ok && cch + 16 <= a.cstore;
 
-  // ---- epilogue of one finished output plane q: + bias, bf16, two 16-byte stores per lane and row; statistics of
-  //      (z - bias) over the valid voxels stay in registers (per lane: 16 channels of its voxel column)
+  auto pack_row = [&](const f32x16& s, uint32_t (&w)[8], const bool stats) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+      const float v0 = s[i], v1 = s[i + 1];                           // accumulator units (fp8: z / deq); sums are rescaled once, at the end
+#ifndef MARCH_DIAG_NO_STATS
+      if (stats) { s1[i] += v0; s2[i] += v0 * v0; s1[i + 1] += v1; s2[i + 1] += v1 * v1; }
+#endif
+      w[i >> 1] = F8 ? ((uint32_t)f32_to_bf16_bits(v0 * deq) | ((uint32_t)f32_to_bf16_bits(v1 * deq) << 16))
+                     : ((uint32_t)f32_to_bf16_bits(v0) | ((uint32_t)f32_to_bf16_bits(v1) << 16));
+    }
+  };
+  // ---- epilogue of one finished output plane q (generic form): bf16, two 16-byte stores per lane and row
   auto store_plane = [&](f32x16 (&s)[4], int q) __attribute__((always_inline)) {
 #pragma unroll
     for (int row = 0; row < 4; ++row) {
@@ -150,150 +198,139 @@ __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, co
       nstat += vox_ok ? 1 : 0;
       T* dst = reinterpret_cast<T*>(a.y) + ((((long long)tn * a.dy + q) * a.hy + gh) * a.wy + w0 + r) * a.ldy + cch;
       uint32_t w[8];
-#pragma unroll
-      for (int i = 0; i < 16; i += 2) {
-        const float v0 = s[row][i], v1 = s[row][i + 1];
-#ifndef MARCH_DIAG_NO_STATS
-        if (vox_ok) { s1[i] += v0; s2[i] += v0 * v0; s1[i + 1] += v1; s2[i + 1] += v1 * v1; }
-#endif
-        w[i >> 1] = (uint32_t)f32_to_bf16_bits(v0) | ((uint32_t)f32_to_bf16_bits(v1) << 16);
-      }
-#ifndef MARCH_DIAG_NO_GSTORE
+      pack_row(s[row], w, vox_ok);
       if (st0) *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
       if (st1) *reinterpret_cast<uint4*>(dst + 8) = make_uint4(w[4], w[5], w[6], w[7]);
-#else
-      asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(dst));
-#endif
+    }
+  };
+  auto init_row = [&](f32x16& s) __attribute__((always_inline)) {    // first contribution to an output row: C = bias
+    const float4* bp = reinterpret_cast<const float4*>(blds + 16 * h);
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+      const float4 q = bp[i4];
+      s[4 * i4] = q.x; s[4 * i4 + 1] = q.y; s[4 * i4 + 2] = q.z; s[4 * i4 + 3] = q.w;
     }
   };
 
-  // ---- one (kd) block of a march step: 2 chunks x 3 kw groups of {3 weight fragments (kh), 6 activation fragments
-  //      (halo rows), 12 MFMAs}; the next group's 9 fragment reads are issued ahead of this group's MFMAs (one wave per
-  //      SIMD: nothing else hides the LDS latency)
-  struct Group { Frag<T> b[3], x[6]; };
-  auto load_group = [&](Group& g, const char* pl, const int kd, const int gi) __attribute__((always_inline)) {
-    const int c = gi / 3, kw = gi - c * 3;
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) g.b[kh].load(wlane + (c * 27 + kd * 9 + kh * 3 + kw) * 1024);
-#pragma unroll
-    for (int hy = 0; hy < 6; ++hy) g.x[hy].load(pl + aoff[kw][c] + hy * (HC * 64));
+  // ---- fragment groups.  The NEXT group's reads are issued ahead of this group's MFMAs (one wave per SIMD: nothing else
+  //      hides the LDS latency); hipcc's scheduler would sink every read next to its first use, so the order is pinned
+  //      with sched_group_barrier.
+  //      bf16 group gi (6 per kd block) = (chunk, kw): 3 weight + 6 activation fragments, 12 MFMAs
+  //      fp8  group gi (5 per kd block) = tap pair   : 1 weight + 4 activation fragments (2 reads each), 4 MFMAs
+  constexpr int NG = F8 ? 5 : 6, NRD = F8 ? 10 : 9, NMM = F8 ? 4 : 12;
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  struct Group { uint4 b[3], x[6]; i32x8 w8, x8[4]; };                // (bf16: b / x; fp8: w8 / x8 -- the unused members vanish)
+  auto ld32 = [&](const char* p0, const char* p1) __attribute__((always_inline)) {   // two 16-B pieces -> one 32-B MFMA operand
+    const i32x4 lo = *reinterpret_cast<const i32x4*>(p0), hi = *reinterpret_cast<const i32x4*>(p1);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   };
-  auto mma_group = [&](const Group& g, f32x16 (&s)[4], const bool zero) __attribute__((always_inline)) {
+  auto load_group = [&](Group& g, const char* pl, const int kd, const int gi) __attribute__((always_inline)) {
+    if constexpr (F8) {
+      g.w8 = ld32(wlane + ((kd * 5 + gi) * 2) * 1024, wlane + ((kd * 5 + gi) * 2 + 1) * 1024);
 #pragma unroll
-    for (int hy = 0; hy < 6; ++hy)
+      for (int row = 0; row < 4; ++row) g.x8[row] = ld32(pl + aoff[gi][0] + row * (HC * VB), pl + aoff[gi][1] + row * (HC * VB));
+    } else {
+      const int c = gi / 3, kw = gi - c * 3;
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int row = hy - kh;
-        if (row >= 0 && row < 4) {
-          if (zero && kh == 0) {                                      // first contribution to this row: C = bias
-            f32x16 z;
-            const float4* bp = reinterpret_cast<const float4*>(blds + 16 * h);
+      for (int kh = 0; kh < 3; ++kh) g.b[kh] = *reinterpret_cast<const uint4*>(wlane + (c * 27 + kd * 9 + kh * 3 + kw) * 1024);
 #pragma unroll
-            for (int i4 = 0; i4 < 4; ++i4) {
-              const float4 q = bp[i4];
-              z[4 * i4] = q.x; z[4 * i4 + 1] = q.y; z[4 * i4 + 2] = q.z; z[4 * i4 + 3] = q.w;
-            }
-            s[row] = z;
+      for (int hy = 0; hy < 6; ++hy) g.x[hy] = *reinterpret_cast<const uint4*>(pl + aoff[kw][c] + hy * (HC * VB));
+    }
+  };
+  auto mma_group = [&](const Group& g, f32x16 (&s)[4], const bool fresh) __attribute__((always_inline)) {
+    if constexpr (F8) {
+#pragma unroll
+      for (int row = 0; row < 4; ++row) {
+        if (fresh) init_row(s[row]);
+        s[row] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(g.w8, g.x8[row], s[row], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      }
+    } else {
+#pragma unroll
+      for (int hy = 0; hy < 6; ++hy)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int row = hy - kh;
+          if (row >= 0 && row < 4) {
+            if (fresh && kh == 0) init_row(s[row]);
+            s[row] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, g.b[kh]), __builtin_bit_cast(bf16x8, g.x[hy]),
+                                                             s[row], 0, 0, 0);              // rows = output channels, columns = voxels
           }
-          mma16(g.b[kh], g.x[hy], s[row]);                            // rows = output channels, columns = voxels
+        }
+    }
+  };
+  auto pin_pipeline = [&](const int ngroups) __attribute__((always_inline)) {
+#ifdef MARCH_F8_NOPIN
+    if constexpr (F8) return;
+#endif
+    __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+#pragma unroll
+    for (int gi = 0; gi < ngroups; ++gi) {
+#pragma unroll
+      for (int k = 0; k < NMM; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (gi + 1 < ngroups) {
+          if constexpr (F8) {
+            if (k < 2) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          } else if (k < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
       }
+    }
   };
   auto block = [&](const char* pl, f32x16 (&s)[4], const int kd, const bool fresh) __attribute__((always_inline)) {
-    Group g0, g1;
-    load_group(g0, pl, kd, 0);
+    Group g[2];
+    load_group(g[0], pl, kd, 0);
 #pragma unroll
-    for (int gi = 0; gi < 6; gi += 2) {
-      load_group(g1, pl, kd, gi + 1);
-      mma_group(g0, s, fresh && gi == 0);
-      if (gi + 2 < 6) load_group(g0, pl, kd, gi + 2);
-      mma_group(g1, s, false);
+    for (int gi = 0; gi < NG; ++gi) {
+      if (gi + 1 < NG) load_group(g[(gi + 1) & 1], pl, kd, gi + 1);
+      mma_group(g[gi & 1], s, fresh && gi == 0);
     }
-    // hipcc's scheduler sinks every read next to its first use (it minimises live registers), which exposes the LDS
-    // latency ~100 times per plane.  Pin the software pipeline: group 0's 9 reads, then each group's 12 MFMAs with the
-    // NEXT group's 9 reads interleaved one per MFMA.
-    __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
-#pragma unroll
-    for (int gi = 0; gi < 5; ++gi) {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+    pin_pipeline(NG);
   };
   // ---- the steady-state step (all three output planes inside the segment, footprint inside the volume) as ONE basic
-  //      block: the next plane's 10 LDS-DMA instructions, 18 chained fragment groups (kd = 2, 1, 0) and the epilogue of the
-  //      plane that kd = 2 completes, with the issue order pinned: per MFMA one fragment read of the NEXT group and up to
-  //      two VALU instructions (epilogue arithmetic), one DMA / store per group.  One wave per SIMD: what is not placed
-  //      between MFMAs is not overlapped with anything.
+  //      block: the next plane's LDS-DMA, 3 x NG chained fragment groups (kd = 2, 1, 0) and the epilogue of the plane that
+  //      kd = 2 completes (buffer stores: lanes that must not store get an out-of-range offset, no branch).
   const auto rsy = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (int)((((long long)a.n * a.dy * a.hy * a.wy - 1) * a.ldy + a.cstore) * 2), 0x00020000);
   const int yrow = ((4 * wave) * a.wy + w0 + r) * a.ldy * 2 + cch * 2;        // byte offset of this lane's voxel in row 0 of a plane's footprint
   auto full_step = [&](int p, f32x16 (&s_m1)[4], f32x16 (&s_0)[4], f32x16 (&s_p1)[4]) __attribute__((always_inline)) {
+#ifndef MARCH_DIAG_NO_DMA
     load_plane(p + 1);
-    const char* pl = smem + (p & 1) * kMarchPlane;
+#endif
+    const char* pl = smem + (p & 1) * Cfg::PLANE;
     Group g[2];
     load_group(g[0], pl, 2, 0);
 #pragma unroll
-    for (int gi = 0; gi < 18; ++gi) {
-      if (gi + 1 < 18) load_group(g[(gi + 1) & 1], pl, 2 - (gi + 1) / 6, (gi + 1) % 6);
-      if (gi < 6) mma_group(g[gi & 1], s_m1, false);
-      else if (gi < 12) mma_group(g[gi & 1], s_0, false);
-      else mma_group(g[gi & 1], s_p1, gi == 12);
+    for (int gi = 0; gi < 3 * NG; ++gi) {
+      if (gi + 1 < 3 * NG) load_group(g[(gi + 1) & 1], pl, 2 - (gi + 1) / NG, (gi + 1) % NG);
+      if (gi < NG) mma_group(g[gi & 1], s_m1, false);
+      else if (gi < 2 * NG) mma_group(g[gi & 1], s_0, false);
+      else mma_group(g[gi & 1], s_p1, gi == 2 * NG);
 #ifdef MARCH_DIAG_NO_STORE
-      if (gi == 5) asm volatile("" :: "v"(s_m1[0][0]), "v"(s_m1[1][5]), "v"(s_m1[2][9]), "v"(s_m1[3][15]));
+      if (gi == NG - 1) asm volatile("" :: "v"(s_m1[0][0]), "v"(s_m1[1][5]), "v"(s_m1[2][9]), "v"(s_m1[3][15]));
 #else
-      if (gi == MARCH_EPI_AT) {                                       // output plane p - 1 is complete
+      if (gi == NG - 1) {                                             // output plane p - 1 is complete
         nstat += 4;
         const int ybase = ((tn * a.dy + (p - 1)) * a.hy + h0) * a.wy * a.ldy * 2;
 #pragma unroll
         for (int row = 0; row < 4; ++row) {
           typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
           uint32_t w[8];
-#pragma unroll
-          for (int i = 0; i < 16; i += 2) {
-            const float v0 = s_m1[row][i], v1 = s_m1[row][i + 1];
-#ifndef MARCH_DIAG_NO_STATS
-            s1[i] += v0; s2[i] += v0 * v0; s1[i + 1] += v1; s2[i + 1] += v1 * v1;
+#ifdef MARCH_EPI_FENCE
+          __builtin_amdgcn_sched_barrier(MARCH_EPI_FENCE);
 #endif
-            w[i >> 1] = (uint32_t)f32_to_bf16_bits(v0) | ((uint32_t)f32_to_bf16_bits(v1) << 16);
-          }
-          const int off = yrow + row * a.wy * a.ldy * 2;
+          pack_row(s_m1[row], w, true);
+          // (the plane's base goes into the VECTOR offset, soffset = 0: with a register soffset hipcc places a VALU write
+          //  of the store's data registers right behind a 16-byte store -- on gfx950 the store then read the NEW values
+          //  in its last lanes; with a constant soffset the compiler's own hazard rule keeps the wait state)
+          const int off = ybase + yrow + row * a.wy * a.ldy * 2;
           u32x4 lo = {w[0], w[1], w[2], w[3]}, hi = {w[4], w[5], w[6], w[7]};
-#ifndef MARCH_DIAG_NO_GSTORE
-          __builtin_amdgcn_raw_buffer_store_b128(lo, rsy, st0 ? off : (int)0x80000000, ybase, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(hi, rsy, st1 ? off + 16 : (int)0x80000000, ybase, 0);
-#else
-          asm volatile("" :: "v"(lo), "v"(hi), "v"(off));
-#endif
+          __builtin_amdgcn_raw_buffer_store_b128(lo, rsy, st0 ? off : (int)0x80000000, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(hi, rsy, st1 ? off + 16 : (int)0x80000000, 0, 0);
         }
       }
 #endif
     }
-#if MARCH_SGB
-    __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
-#endif
-#pragma unroll
-    for (int gi = 0; gi < (MARCH_SGB ? 18 : 0); ++gi) {
-#pragma unroll
-      for (int k = 0; k < 12; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (gi < 17 && k < 9) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#if MARCH_SGB_VMEM == 1
-        if (k == 10) __builtin_amdgcn_sched_group_barrier(0x030, 1, 0);       // one DMA / store per group
-#elif MARCH_SGB_VMEM == 2
-        if (gi == 0 && k < 10) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // the next plane's DMA: first thing, one per MFMA
-        if (gi == 6 && k < 8) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);    // the finished plane's stores: right behind kd = 2
-#elif MARCH_SGB_VMEM == 3
-        if (gi == 6 && k < 8) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
-#endif
-#if MARCH_SGB_VALU
-        __builtin_amdgcn_sched_group_barrier(0x002, MARCH_SGB_VALU, 0);
-#endif
-      }
-    }
+    pin_pipeline(3 * NG);
     __syncthreads();
   };
   auto step = [&](int p, f32x16 (&s_m1)[4], f32x16 (&s_0)[4], f32x16 (&s_p1)[4]) __attribute__((always_inline)) {
@@ -301,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, co
 #ifndef MARCH_DIAG_NO_DMA
     if (p + 1 <= d1) load_plane(p + 1);                               // lands under this plane's MFMAs
 #endif
-    const char* pl = smem + (p & 1) * kMarchPlane;
+    const char* pl = smem + (p & 1) * Cfg::PLANE;
     if (p - 1 >= d0) {                                                // kd = 2 completes output plane p - 1
       block(pl, s_m1, 2, false);
 #ifndef MARCH_DIAG_NO_STORE
@@ -324,36 +361,33 @@ __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, co
   //  * anything else (volume border, last short segment): the generic step with its wave-uniform branches.
   const bool interior = h0 + kMarchFH <= a.ho && w0 + kMarchFW <= a.wo && st1;
   const int slen = d1 - d0;
-#ifndef MARCH_NO_FAST
   if (interior && slen >= 5 && slen % 3 == 2) {
     f32x16 sa[4], sb[4], sc[4];
     int p = d0 - 1;
     load_plane(p + 1);
-    block(smem + (p & 1) * kMarchPlane, sa, 0, true);                 // input plane d0 - 1 -> output d0
+    block(smem + (p & 1) * Cfg::PLANE, sa, 0, true);                  // input plane d0 - 1 -> output d0
     __syncthreads();
     ++p;
     load_plane(p + 1);
-    block(smem + (p & 1) * kMarchPlane, sa, 1, false);                // input plane d0 -> outputs d0, d0 + 1
-    block(smem + (p & 1) * kMarchPlane, sb, 0, true);
+    block(smem + (p & 1) * Cfg::PLANE, sa, 1, false);                 // input plane d0 -> outputs d0, d0 + 1
+    block(smem + (p & 1) * Cfg::PLANE, sb, 0, true);
     __syncthreads();
     ++p;
-    for (int t = 0; t < (slen - 2) / 3; ++t) {
+    for (int t3 = 0; t3 < (slen - 2) / 3; ++t3) {
       full_step(p, sa, sb, sc);
       full_step(p + 1, sb, sc, sa);
       full_step(p + 2, sc, sa, sb);
       p += 3;
     }
     load_plane(p + 1);                                                // p = d1 - 1 (plane d1 may lie outside: zeros)
-    block(smem + (p & 1) * kMarchPlane, sa, 2, false);
+    block(smem + (p & 1) * Cfg::PLANE, sa, 2, false);
     store_plane(sa, p - 1);
-    block(smem + (p & 1) * kMarchPlane, sb, 1, false);
+    block(smem + (p & 1) * Cfg::PLANE, sb, 1, false);
     __syncthreads();
     ++p;
-    block(smem + (p & 1) * kMarchPlane, sb, 2, false);                // p = d1
+    block(smem + (p & 1) * Cfg::PLANE, sb, 2, false);                 // p = d1
     store_plane(sb, p - 1);
-  } else
-#endif
-  {
+  } else {
     f32x16 acc[3][4];
     const int first = d0 - 1;
     const int pa = (first >= 0 ? first / 3 : -((-first + 2) / 3)) * 3;     // floor to a multiple of 3
@@ -372,7 +406,8 @@ __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, co
     const float cnt = (float)nstat;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const float b = blds[16 * h + i];                               // sums of z -> sums of (z - bias)
+      const float b = blds[16 * h + i] * deq;                         // sums of z -> sums of (z - bias)
+      if constexpr (F8) { s1[i] *= deq; s2[i] *= deq * deq; }
       s2[i] = s2[i] - 2.f * b * s1[i] + cnt * b * b;
       s1[i] = s1[i] - cnt * b;
 #pragma unroll

@@ -64,6 +64,7 @@ struct WpackArgs {
   long long s_co, s_ci, s_k0, s_k1, s_k2;
   int tb0, tb1, tb2, ts0, ts1, ts2;
   int s2d_mode, s2d_cp;   // 1: the GEMM cin index is (block, channel) of a space-to-depth tensor; 2: the cout index is
+  const float* q_amax;    // fp8 packings: per-tensor max |w| (device), values are stored as w * 224 / amax
 };
 template <typename T>
 __global__ __launch_bounds__(256) void wpack_kernel(const WpackArgs a) {
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(256) void wpack_kernel(const WpackArgs a) {
     v = a.src[cor * a.s_co + ci * a.s_ci + (a.tb0 + a.ts0 * td + (blk >> 2)) * a.s_k0 +
               (a.tb1 + a.ts1 * th + ((blk >> 1) & 1)) * a.s_k1 + (a.tb2 + a.ts2 * tw + (blk & 1)) * a.s_k2];
   }
+  if constexpr (sizeof(T) == 1) v *= fp8_scale_of(a.q_amax);
   Elem<T>::store(reinterpret_cast<T*>(a.dst) + idx, v);
 }
 
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(256) void wpack_multi_kernel(const WpackMulti m) {
       v = a.src[cor * a.s_co + ci * a.s_ci + (a.tb0 + a.ts0 * td + (blk >> 2)) * a.s_k0 +
                 (a.tb1 + a.ts1 * th + ((blk >> 1) & 1)) * a.s_k1 + (a.tb2 + a.ts2 * tw + (blk & 1)) * a.s_k2];
     }
+    if constexpr (sizeof(T) == 1) v *= fp8_scale_of(a.q_amax);
     Elem<T>::store(reinterpret_cast<T*>(a.dst) + idx, v);
   }
 }
@@ -732,16 +735,19 @@ int mi355_weight_pack(const mi355_wpack_desc* d, void* stream) {
                 "weight_pack: bad extents");
   MI355_REQUIRE(d->s2d_mode >= 0 && d->s2d_mode <= 2 && (d->s2d_mode == 0 || (d->s2d_cp > 0 && d->s2d_cp % 16 == 0)),
                 "weight_pack: bad space-to-depth mode");
-  MI355_REQUIRE(d->dtype == MI355_DT_F32 || d->dtype == MI355_DT_BF16, "weight_pack: bad dtype");
+  MI355_REQUIRE(d->dtype == MI355_DT_F32 || d->dtype == MI355_DT_BF16 || d->dtype == MI355_DT_FP8, "weight_pack: bad dtype");
+  MI355_REQUIRE(d->dtype != MI355_DT_FP8 || d->q_amax, "weight_pack: fp8 packing needs q_amax");
   WpackArgs a;
   a.src = d->src; a.dst = d->dst; a.cout = d->cout; a.cin = d->cin; a.coutp = d->coutp; a.cinp = d->cinp; a.ks = d->ks;
   a.s_co = d->s_co; a.s_ci = d->s_ci; a.s_k0 = d->s_k[0]; a.s_k1 = d->s_k[1]; a.s_k2 = d->s_k[2];
   a.tb0 = d->tbase[0]; a.tb1 = d->tbase[1]; a.tb2 = d->tbase[2];
   a.ts0 = d->tstep[0]; a.ts1 = d->tstep[1]; a.ts2 = d->tstep[2];
   a.s2d_mode = d->s2d_mode; a.s2d_cp = d->s2d_cp;
+  a.q_amax = d->q_amax;
   const long long total = (long long)d->cinp * d->ks * d->ks * d->ks * d->coutp;
   dim3 grid((unsigned)((total + 255) / 256));
   if (d->dtype == MI355_DT_F32) hipLaunchKernelGGL(wpack_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else if (d->dtype == MI355_DT_FP8) hipLaunchKernelGGL(wpack_kernel<fp8_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(wpack_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
   return mi355_check_launch("weight_pack");
 }
@@ -779,7 +785,9 @@ __global__ __launch_bounds__(256) void wpack_dense3_multi_kernel(const WpackMult
   for (int tap = 0; tap < NT; ++tap) {
     const int td = tap / 9, th = (tap / 3) % 3, tw = tap % 3;
     const int ts = (a.tb0 + a.ts0 * td) * 9 + (a.tb1 + a.ts1 * th) * 3 + (a.tb2 + a.ts2 * tw);
-    Elem<T>::store(dst + (long long)tap * a.coutp * 16, tile[rl * ROW + cl * NT + ts]);
+    float v = tile[rl * ROW + cl * NT + ts];
+    if constexpr (sizeof(T) == 1) v *= fp8_scale_of(a.q_amax);
+    Elem<T>::store(dst + (long long)tap * a.coutp * 16, v);
   }
 }
 
@@ -863,13 +871,14 @@ static int fill_wpack(const mi355_wpack_desc* d, WpackArgs* a) {
   a->tb0 = d->tbase[0]; a->tb1 = d->tbase[1]; a->tb2 = d->tbase[2];
   a->ts0 = d->tstep[0]; a->ts1 = d->tstep[1]; a->ts2 = d->tstep[2];
   a->s2d_mode = d->s2d_mode; a->s2d_cp = d->s2d_cp;
+  a->q_amax = d->q_amax;
   return MI355_OK;
 }
 
 int mi355_weight_pack_multi(const mi355_wpack_desc* descs, int32_t n, void* stream) {
   MI355_REQUIRE(descs && n > 0, "weight_pack_multi: bad argument");
   const int dtype = descs[0].dtype;
-  MI355_REQUIRE(dtype == MI355_DT_F32 || dtype == MI355_DT_BF16, "weight_pack_multi: bad dtype");
+  MI355_REQUIRE(dtype == MI355_DT_F32 || dtype == MI355_DT_BF16 || dtype == MI355_DT_FP8, "weight_pack_multi: bad dtype");
   // three passes over the list: dense 3x3x3 packings and the space-to-depth k4 packings go through their
   // LDS-transposing kernels, the rest through the gather
   for (int pass = 0; pass < 3; ++pass) {
@@ -901,10 +910,12 @@ int mi355_weight_pack_multi(const mi355_wpack_desc* descs, int32_t n, void* stre
         MI355_REQUIRE(patches < (1ll << 31), "weight_pack_multi: too many patches");
         dim3 grid((unsigned)patches, cnt);
         if (dtype == MI355_DT_F32) wpack_dense3_multi_kernel<float><<<grid, dim3(256), 0, (hipStream_t)stream>>>(m);
+        else if (dtype == MI355_DT_FP8) wpack_dense3_multi_kernel<fp8_t><<<grid, dim3(256), 0, (hipStream_t)stream>>>(m);
         else wpack_dense3_multi_kernel<bf16_t><<<grid, dim3(256), 0, (hipStream_t)stream>>>(m);
       } else if (want_s2d) {
         MI355_REQUIRE(patches < (1ll << 31), "weight_pack_multi: too many patches");
         dim3 grid((unsigned)patches, cnt);
+        MI355_REQUIRE(dtype != MI355_DT_FP8, "weight_pack_multi: no fp8 space-to-depth packing");
         if (dtype == MI355_DT_F32) wpack_s2d_multi_kernel<float><<<grid, dim3(256), 0, (hipStream_t)stream>>>(m);
         else wpack_s2d_multi_kernel<bf16_t><<<grid, dim3(256), 0, (hipStream_t)stream>>>(m);
       } else {
@@ -912,6 +923,7 @@ int mi355_weight_pack_multi(const mi355_wpack_desc* descs, int32_t n, void* stre
         if (nb > 512) nb = 512;
         dim3 grid((unsigned)nb, cnt);
         if (dtype == MI355_DT_F32) hipLaunchKernelGGL(wpack_multi_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, m);
+        else if (dtype == MI355_DT_FP8) hipLaunchKernelGGL(wpack_multi_kernel<fp8_t>, grid, dim3(256), 0, (hipStream_t)stream, m);
         else hipLaunchKernelGGL(wpack_multi_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, m);
       }
     }
@@ -1165,6 +1177,144 @@ int mi355_mfma_selftest(float* out_f32_1024, float* out_bf16_1024, void* stream)
   MI355_REQUIRE(out_f32_1024 && out_bf16_1024, "selftest: null pointer");
   hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out_f32_1024, out_bf16_1024);
   return mi355_check_launch("selftest");
+}
+
+}  // extern "C"
+
+namespace {
+// ------------------------------------------------------------------ fp8 operand preparation
+__device__ __forceinline__ void amax_commit(float m, float* out) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));   // m >= 0: bit order = value order
+}
+__global__ __launch_bounds__(256) void amax_f32_kernel(const float* __restrict__ x, long long n, float* out) {
+  float m = 0.f;
+  const long long stride = (long long)gridDim.x * 256 * 4;
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n) {
+      const float4 v = *reinterpret_cast<const float4*>(x + i);
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    } else {
+      for (long long j = i; j < n; ++j) m = fmaxf(m, fabsf(x[j]));
+    }
+  }
+  amax_commit(m, out);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void amax_act_kernel(const T* __restrict__ x, int ld, int c, long long rows, float* out) {
+  constexpr int EPV = Elem<T>::kPer16B;
+  const int lpr = c / EPV;
+  const long long total = rows * lpr, stride = (long long)gridDim.x * 256;
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const long long row = i / lpr;
+    const int piece = (int)(i - row * lpr);
+    Vec16<T> v;
+    v.load(x + row * ld + piece * EPV);
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) m = fmaxf(m, fabsf(v.f[j]));
+  }
+  amax_commit(m, out);
+}
+// 16 channels per thread: two 16-B loads of bf16 (four of f32), one 16-B store of e4m3
+template <typename T>
+__global__ __launch_bounds__(256) void cast_fp8_kernel(const T* __restrict__ x, int ld, int c, long long rows,
+                                                        const float* __restrict__ amax, uint8_t* __restrict__ dst, int ld_dst) {
+  constexpr int EPV = Elem<T>::kPer16B, NV = 16 / EPV;
+  const float sc = fp8_scale_of(amax);
+  const int gpr = c / 16;
+  const long long total = rows * gpr, stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const long long row = i / gpr;
+    const int g = (int)(i - row * gpr);
+    float f[16];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      Vec16<T> v;
+      v.load(x + row * ld + g * 16 + k * EPV);
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) f[k * EPV + j] = v.f[j] * sc;
+    }
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      w[k] = cvt_pk_fp8(f[4 * k], f[4 * k + 1], 0u, false);
+      w[k] = cvt_pk_fp8(f[4 * k + 2], f[4 * k + 3], w[k], true);
+    }
+    *reinterpret_cast<uint4*>(dst + row * ld_dst + g * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+// D[i][j] = sum_k A[i][k] B[k][j], 32 x 32 x 64, A[i][k] = ((i + k) % 5) - 2, B[k][j] = ((2 k + j) % 7) - 3 (exact in e4m3)
+__global__ void fp8_selftest_kernel(float* out) {
+  typedef int i32x8 __attribute__((ext_vector_type(8)));
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  uint32_t wa[8], wb[8];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    float fa[4], fb[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int k = 32 * h + 4 * w + b;
+      fa[b] = (float)(((r + k) % 5) - 2);
+      fb[b] = (float)(((2 * k + r) % 7) - 3);
+    }
+    wa[w] = cvt_pk_fp8(fa[2], fa[3], cvt_pk_fp8(fa[0], fa[1], 0u, false), true);
+    wb[w] = cvt_pk_fp8(fb[2], fb[3], cvt_pk_fp8(fb[0], fb[1], 0u, false), true);
+  }
+  const i32x8 a = {(int)wa[0], (int)wa[1], (int)wa[2], (int)wa[3], (int)wa[4], (int)wa[5], (int)wa[6], (int)wa[7]};
+  const i32x8 b = {(int)wb[0], (int)wb[1], (int)wb[2], (int)wb[3], (int)wb[4], (int)wb[5], (int)wb[6], (int)wb[7]};
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) out[acc_row(i, h) * 32 + r] = acc[i];
+}
+}  // namespace
+
+extern "C" {
+
+int mi355_amax_f32(const float* x, int64_t n, float* amax, void* stream) {
+  MI355_REQUIRE(x && amax && n > 0, "amax_f32: bad argument");
+  if (hipMemsetAsync(amax, 0, 4, (hipStream_t)stream) != hipSuccess) { mi355_set_error("amax: memset failed"); return MI355_ERR_HIP; }
+  long long nb = (n + 1023) / 1024;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(amax_f32_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, (long long)n, amax);
+  return mi355_check_launch("amax_f32");
+}
+
+int mi355_amax_act(const void* x, int32_t ld, int32_t c, int64_t rows, int32_t dtype, float* amax, void* stream) {
+  MI355_REQUIRE(x && amax && rows > 0, "amax_act: bad argument");
+  int rc = check_rows(c, ld, dtype, "amax_act");
+  if (rc) return rc;
+  if (hipMemsetAsync(amax, 0, 4, (hipStream_t)stream) != hipSuccess) { mi355_set_error("amax: memset failed"); return MI355_ERR_HIP; }
+  const int epv = dtype == MI355_DT_F32 ? 4 : 8;
+  long long nb = (rows * (c / epv) + 256 * 8 - 1) / (256 * 8);
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  if (dtype == MI355_DT_F32) hipLaunchKernelGGL(amax_act_kernel<float>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float*)x, ld, c, (long long)rows, amax);
+  else hipLaunchKernelGGL(amax_act_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, c, (long long)rows, amax);
+  return mi355_check_launch("amax_act");
+}
+
+int mi355_cast_fp8(const void* src, int32_t ld_src, int32_t c, int64_t rows, int32_t src_dtype, const float* amax,
+                   void* dst, int32_t ld_dst, void* stream) {
+  MI355_REQUIRE(src && dst && amax && rows > 0 && ld_dst >= c && ld_dst % 16 == 0, "cast_fp8: bad argument");
+  int rc = check_rows(c, ld_src, src_dtype, "cast_fp8");
+  if (rc) return rc;
+  long long nb = (rows * (c / 16) + 256 * 4 - 1) / (256 * 4);
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  if (src_dtype == MI355_DT_F32) hipLaunchKernelGGL(cast_fp8_kernel<float>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float*)src, ld_src, c, (long long)rows, amax, (uint8_t*)dst, ld_dst);
+  else hipLaunchKernelGGL(cast_fp8_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ld_src, c, (long long)rows, amax, (uint8_t*)dst, ld_dst);
+  return mi355_check_launch("cast_fp8");
+}
+
+int mi355_fp8_selftest(float* out_1024, void* stream) {
+  MI355_REQUIRE(out_1024, "fp8_selftest: null pointer");
+  hipLaunchKernelGGL(fp8_selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out_1024);
+  return mi355_check_launch("fp8_selftest");
 }
 
 }  // extern "C"

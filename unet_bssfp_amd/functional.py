@@ -69,6 +69,8 @@ def repack_weights(module: torch.nn.Module):
             for e in spec.cache.stale():
                 by_dtype.setdefault(e[3].dtype, []).append(e[3])
                 entries.append(e)
+                if len(e[1]) > 3:                         # e4m3 packing: its per-tensor amax follows the new weights first
+                    ops.amax_f32(e[2].detach(), out=e[1][3])
     for descs in by_dtype.values():
         ops.weight_pack_multi(descs)
     for e in entries:
@@ -255,6 +257,29 @@ class ConvSpec:
             w.detach(), self.cin, self.cout, k, k ** 3, self.cin * k ** 3, (k * k, k, 1), (k - 1,) * 3, (-1,) * 3,
             dtype, cinp, reuse=r))
 
+    # e4m3 packings (per-tensor scale 224 / max |w|): value = (packed, coutp, cinp, amax)
+    def _fp8(self, key, w, builder):
+        def build(reuse):
+            amax = ops.amax_f32(w.detach(), out=self._amax.get(key))
+            self._amax[key] = amax
+            packed, coutp, cinp = builder(reuse, amax)
+            return packed, coutp, cinp, amax
+        if not hasattr(self, "_amax"):
+            self._amax = {}
+        return self.cache.get(key, w, build)
+
+    def w_fwd8(self, w, cinp):
+        k = self.ks
+        return self._fp8(("fwd8", cinp), w, lambda r, amax: ops.weight_pack(
+            w.detach(), self.cout, self.cin, k, self.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (1, 1, 1),
+            ops.FP8, cinp, reuse=r, q_amax=amax))
+
+    def w_dgrad8(self, w, cinp):
+        k = self.ks
+        return self._fp8(("dgrad8", cinp), w, lambda r, amax: ops.weight_pack(
+            w.detach(), self.cin, self.cout, k, k ** 3, self.cin * k ** 3, (k * k, k, 1), (k - 1,) * 3, (-1,) * 3,
+            ops.FP8, cinp, reuse=r, q_amax=amax))
+
     def w_dgrad_s2(self, w, dtype, cinp, cls):
         # k4 s2 p1 transposed: parity class p per dim uses taps {3,1} (p=0) or {2,0} (p=1)
         k = self.ks
@@ -302,7 +327,7 @@ class ConvFn(Function):
 
     @staticmethod
     def forward(ctx, x0, x1, weight, bias, spec: ConvSpec, want_stats: bool, zero_bias_grad: bool = False,
-                s2d_cp: int = 0):
+                s2d_cp: int = 0, fp8: bool = False):
         x0 = ops.as_act(x0)
         x1 = ops.as_act(x1) if x1 is not None else None
         n, di, hi, wi, c0 = x0.shape
@@ -327,6 +352,19 @@ class ConvFn(Function):
                 part = torch.empty((tiles, 2, coutp), dtype=torch.float32, device=dev)
             ops.conv_fwd(x0, None, wp, coutp, bp, 2, 1, (0, 0, 0), out, (do_, ho, wo), stats=part,
                          real=(spec.cin, spec.cout))
+        elif (fp8 and spec.kind == "conv" and spec.ks == 3 and spec.stride == 1 and spec.pad == 1 and x1 is None
+              and dtype == torch.bfloat16 and ops.conv_fp8_supported(x0, round_up(spec.cout, 32), out, (do_, ho, wo))):
+            # BASELINE.json configs[4]: e4m3 operands (per-tensor scales) on the block-scaled MFMA, f32 accumulate, bf16 out
+            wp, coutp, _, amax_w = spec.w_fwd8(weight, c0)
+            amax_x = ops.amax_act(x0)
+            x8 = ops.cast_fp8(x0, amax_x)
+            q = (amax_x, amax_w)
+            bp = bias.detach() if bias is not None else None
+            if want_stats:
+                tiles, _ = ops.conv_num_tiles(x8, None, wp, coutp, 3, 1, (1, 1, 1), out, (do_, ho, wo), fp8=q)
+                part = torch.empty((tiles, 2, coutp), dtype=torch.float32, device=dev)
+            ops.conv_fwd(x8, None, wp, coutp, bp, 3, 1, (1, 1, 1), out, (do_, ho, wo), stats=part,
+                         real=(spec.cin, spec.cout), fp8=q)
         elif spec.kind == "conv":
             wp, coutp, _ = spec.w_fwd(weight, dtype, c0 + c1)
             bp = bias.detach() if bias is not None else None
@@ -351,6 +389,7 @@ class ConvFn(Function):
                                  real=(spec.cin, spec.cout))
         ctx.save_for_backward(x0, x1, weight)
         ctx.spec = spec
+        ctx.fp8 = fp8
         ctx.has_bias = bias is not None
         ctx.bias_param, ctx.weight_param = bias, weight    # (their .grad may live in a GradBuckets buffer: gradsink.py)
         # a normalisation with batch/instance statistics follows: the mean subtraction cancels the bias,
@@ -366,7 +405,7 @@ class ConvFn(Function):
     @once_differentiable
     def backward(ctx, dz, _dpart):
         if dz is None:                        # the conv output did not reach the loss
-            return (None,) * 8
+            return (None,) * 9
         x0, x1, weight = ctx.saved_tensors
         spec: ConvSpec = ctx.spec
         dz = ops.as_act(dz)
@@ -383,6 +422,12 @@ class ConvFn(Function):
             if ctx.s2d_cp:
                 wp, coutp, _ = spec.w_dgrad_s2d(weight, dtype, cg, ctx.s2d_cp)
                 ops.conv_fwd(dz, None, wp, coutp, None, 2, 1, (1, 1, 1), dxc, (di, hi, wi), real=(spec.cout, spec.cin))
+            elif (ctx.fp8 and spec.kind == "conv" and k == 3 and spec.stride == 1 and spec.pad == 1 and dtype == torch.bfloat16
+                  and ops.conv_fp8_supported(dz, round_up(c0 + c1, 32), dxc, (di, hi, wi))):
+                wp, coutp, _, amax_w = spec.w_dgrad8(weight, cg)
+                amax_g = ops.amax_act(dz)
+                ops.conv_fwd(ops.cast_fp8(dz, amax_g), None, wp, coutp, None, 3, 1, (1, 1, 1), dxc, (di, hi, wi),
+                             real=(spec.cout, spec.cin), fp8=(amax_g, amax_w))
             elif spec.kind == "conv" and spec.stride == 1:
                 wp, coutp, _ = spec.w_dgrad_s1(weight, dtype, cg, c0 + c1)
                 ops.conv_fwd(dz, None, wp, coutp, None, k, 1, (k - 1 - spec.pad,) * 3, dxc, (di, hi, wi),
@@ -438,7 +483,7 @@ class ConvFn(Function):
                 bsink.written(ctx.bias_param)
             else:
                 db = ops.colsum(dz)[: spec.cout].contiguous()
-        return dx0, dx1, dw, db, None, None, None, None
+        return dx0, dx1, dw, db, None, None, None, None, None
 
 
 # ====================================================================================== norm + act

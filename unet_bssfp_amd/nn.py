@@ -35,9 +35,13 @@ def set_default_compute_dtype(dtype: torch.dtype):
     _DEFAULT_DTYPE = dtype
 
 
+FP8 = "fp8"     # bf16 storage + e4m3 operands for the full-resolution 3x3x3 convolutions (BASELINE.json configs[4])
+
+
 def compute_dtype_from_name(name):
-    """'f32' (parity mode), 'bf16' (throughput mode) -> the torch dtype ``set_compute_dtype`` takes."""
-    if isinstance(name, torch.dtype):
+    """'f32' (parity mode), 'bf16' (throughput mode), 'fp8' (bf16 + e4m3 convolutions where they pay) -> what
+    ``set_compute_dtype`` takes."""
+    if isinstance(name, torch.dtype) or name == FP8:
         return name
     table = {"f32": torch.float32, "fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
     if name not in table:
@@ -48,10 +52,18 @@ def compute_dtype_from_name(name):
 def set_compute_dtype(module: nn.Module, dtype: torch.dtype) -> nn.Module:
     """Arithmetic/storage type of the activations (f32: parity mode, bf16: throughput mode)."""
     dtype = compute_dtype_from_name(dtype)
+    fp8 = dtype == FP8
+    if fp8:
+        dtype = torch.bfloat16
     assert dtype in (torch.float32, torch.bfloat16)
     for m in module.modules():
         if isinstance(m, _Mi355Module):
             m.compute_dtype = dtype
+        if isinstance(m, Conv3d):
+            # e4m3 operands (per-tensor scales, f32 accumulate) for forward and data gradient of the 3x3x3 stride-1 layers
+            # the fp8 kernel covers (32 input channels at full resolution: decided per call); weight gradients, statistics,
+            # master weights and every other layer stay as in the bf16 mode
+            m.fp8 = fp8 and m.kernel_size == (3, 3, 3) and m.stride == (1, 1, 1) and m.padding == (1, 1, 1)
     return module
 
 
@@ -102,6 +114,7 @@ class Conv3d(_Mi355Module):
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels, k, k, k))
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         self.spec = Fn.ConvSpec("conv", in_channels, out_channels, k, s, p)
+        self.fp8 = False
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -113,7 +126,7 @@ class Conv3d(_Mi355Module):
             nn.init.uniform_(self.bias, -bound, bound)
 
     def forward_act(self, x0, x1=None, want_stats=False, zero_bias_grad=False, s2d_cp=0):
-        return Fn.ConvFn.apply(x0, x1, self.weight, self.bias, self.spec, want_stats, zero_bias_grad, s2d_cp)
+        return Fn.ConvFn.apply(x0, x1, self.weight, self.bias, self.spec, want_stats, zero_bias_grad, s2d_cp, self.fp8)
 
     def forward(self, x):
         z, _ = self.forward_act(self._to_act(x))

@@ -10,7 +10,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import DT_BF16, DT_F32
+from ._lib import DT_BF16, DT_F32, DT_FP8
 
 _DT = {torch.float32: DT_F32, torch.bfloat16: DT_BF16}
 
@@ -137,17 +137,26 @@ def unpack_ncdhw_s2d(src: torch.Tensor, c: int, dims, cblk: int, coff: int = 0) 
 
 
 # ------------------------------------------------------------------------------ weights
+FP8 = "fp8"       # dtype marker of the e4m3 packings / operands (stored as torch.uint8)
+
+
 def weight_pack(src: torch.Tensor, cout: int, cin: int, ks: int, s_co: int, s_ci: int,
-                s_k: Sequence[int], tbase: Sequence[int], tstep: Sequence[int], dtype: torch.dtype,
+                s_k: Sequence[int], tbase: Sequence[int], tstep: Sequence[int], dtype,
                 cinp: Optional[int] = None, coutp: Optional[int] = None, s2d_mode: int = 0,
-                s2d_cp: int = 0, reuse: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, int, int]:
+                s2d_cp: int = 0, reuse: Optional[torch.Tensor] = None, q_amax: Optional[torch.Tensor] = None
+                ) -> Tuple[torch.Tensor, int, int]:
     """Returns (packed [cinp/16][ks^3][coutp][16], coutp, cinp).  `reuse`: re-pack in place into an
-    earlier result (keeps the buffer address stable: required for hipGraph replays)."""
+    earlier result (keeps the buffer address stable: required for hipGraph replays).
+    dtype ops.FP8: e4m3 bytes of w * 224 / q_amax[0] (q_amax: device f32[1], see amax_f32)."""
     require_cuda(src)
     assert src.dtype == torch.float32 and src.is_contiguous()
     coutp = round_up(cout, 32) if coutp is None else coutp
     cinp = round_up(cin, 16) if cinp is None else cinp
     shape = (cinp // 16, ks ** 3, coutp, 16)
+    fp8 = dtype == FP8
+    if fp8:
+        assert q_amax is not None
+        dtype = torch.uint8
     if reuse is not None and tuple(reuse.shape) == shape and reuse.dtype == dtype and reuse.device == src.device:
         dst = reuse
     else:
@@ -159,7 +168,8 @@ def weight_pack(src: torch.Tensor, cout: int, cin: int, ks: int, s_co: int, s_ci
     d.s_k = (C.c_int64 * 3)(*s_k)
     d.tbase = (C.c_int32 * 3)(*tbase)
     d.tstep = (C.c_int32 * 3)(*tstep)
-    d.dtype = _DT[dtype]
+    d.dtype = DT_FP8 if fp8 else _DT[dtype]
+    d.q_amax = _ptr(q_amax)
     d.s2d_mode, d.s2d_cp = s2d_mode, s2d_cp
     _lib.check(_lib.load().mi355_weight_pack(C.byref(d), _stream()), "weight_pack")
     LAST_WPACK_DESC[0] = d
@@ -178,7 +188,7 @@ def weight_pack_multi(descs):
 
 
 # ------------------------------------------------------------------------------ convolution
-def _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, stats, cls_cout=0):
+def _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, stats, cls_cout=0, fp8=None):
     d = _lib.ConvDesc()
     n, di, hi, wi, c0 = x0.shape
     d.x0, d.c0, d.ld0 = x0.data_ptr(), c0, act_ld(x0)
@@ -199,13 +209,17 @@ def _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, st
     d.os = os
     d.ooff = (C.c_int32 * 3)(*ooff)
     d.stats_part = _ptr(stats)
-    d.dtype = _DT[x0.dtype]
+    if fp8 is not None:                     # (amax_x, amax_w): x0 / wp are e4m3 bytes, the output stays bf16
+        d.dtype = DT_FP8
+        d.q_amax_x, d.q_amax_w = fp8[0].data_ptr(), fp8[1].data_ptr()
+    else:
+        d.dtype = _DT[x0.dtype]
     d.cls_cout = cls_cout
     return d
 
 
-def conv_num_tiles(x0, x1, wp, coutp, ks, stride, pad, out, grid, os=1, ooff=(0, 0, 0)) -> Tuple[int, int]:
-    d = _conv_desc(x0, x1, wp, coutp, None, ks, stride, pad, out, grid, os, ooff, None)
+def conv_num_tiles(x0, x1, wp, coutp, ks, stride, pad, out, grid, os=1, ooff=(0, 0, 0), fp8=None) -> Tuple[int, int]:
+    d = _conv_desc(x0, x1, wp, coutp, None, ks, stride, pad, out, grid, os, ooff, None, 0, fp8)
     tiles, tps = C.c_int32(0), C.c_int32(0)
     _lib.check(_lib.load().mi355_conv_num_tiles(C.byref(d), C.byref(tiles), C.byref(tps)), "conv_num_tiles")
     return tiles.value, tps.value
@@ -217,11 +231,15 @@ CONV_PROBE = None
 
 
 def conv_fwd(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os=1, ooff=(0, 0, 0), stats=None, real=None,
-             cls_cout=0):
+             cls_cout=0, fp8=None):
+    """fp8 = (amax_x, amax_w): x0 and wp hold e4m3 bytes (cast_fp8 / weight_pack(dtype=FP8)), `out` is bf16."""
     require_cuda(x0, x1, wp, bias, out, stats)
-    assert out.dtype == x0.dtype and wp.dtype == x0.dtype
+    if fp8 is None:
+        assert out.dtype == x0.dtype and wp.dtype == x0.dtype
+    else:
+        assert x0.dtype == torch.uint8 and wp.dtype == torch.uint8 and out.dtype == torch.bfloat16 and x1 is None
     assert bias is None or (bias.dtype == torch.float32 and bias.is_contiguous())
-    d = _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, stats, cls_cout)
+    d = _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, stats, cls_cout, fp8)
     lib = _lib.load()
     need = lib.mi355_conv_workspace_bytes(C.byref(d))
     if need < 0:
@@ -272,6 +290,63 @@ def conv_wgrad(x0, x1, g, grid, gs, goff, ks, stride, pad, dw, cout, cin, s_co, 
     ws = torch.empty((need // 4,), dtype=torch.float32, device=x0.device)
     d.workspace, d.workspace_bytes = ws.data_ptr(), need
     _lib.check(lib.mi355_conv_wgrad(C.byref(d), _stream()), "conv_wgrad")
+
+
+# ------------------------------------------------------------------------------ fp8 operands
+def amax_f32(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """max |x| of a contiguous f32 tensor as a device f32[1] (per-tensor scale of the e4m3 weight packings)."""
+    require_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty((1,), dtype=torch.float32, device=x.device) if out is None else out
+    _lib.check(_lib.load().mi355_amax_f32(x.data_ptr(), x.numel(), out.data_ptr(), _stream()), "amax_f32")
+    return out
+
+
+def amax_act(x: torch.Tensor) -> torch.Tensor:
+    require_cuda(x)
+    n, d, h, w, c = x.shape
+    out = torch.empty((1,), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().mi355_amax_act(x.data_ptr(), act_ld(x), c, n * d * h * w, _DT[x.dtype], out.data_ptr(), _stream()), "amax_act")
+    return out
+
+
+def cast_fp8(x: torch.Tensor, amax: torch.Tensor) -> torch.Tensor:
+    """NDHWC activation -> e4m3 bytes of x * 224 / amax (uint8 tensor of the same shape, one byte per channel)."""
+    require_cuda(x, amax)
+    n, d, h, w, c = x.shape
+    out = torch.empty((n, d, h, w, c), dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.load().mi355_cast_fp8(x.data_ptr(), act_ld(x), c, n * d * h * w, _DT[x.dtype], amax.data_ptr(), out.data_ptr(), c,
+                                          _stream()), "cast_fp8")
+    return out
+
+
+def conv_fp8_supported(x0: torch.Tensor, coutp: int, out: torch.Tensor, grid) -> bool:
+    """Does mi355_conv_fwd take this 3x3x3 stride-1 pad-1 layer with e4m3 operands?  (32 input channels in one source,
+    plain output grid: the marching kernel's layers.)"""
+    n, di, hi, wi, c0 = x0.shape
+    if c0 != 32 or not x0.is_cuda:
+        return False
+    d = _lib.ConvDesc()
+    d.x0, d.c0, d.ld0 = x0.data_ptr(), c0, c0
+    d.x1, d.c1, d.ld1 = None, 0, 0
+    d.n, d.di, d.hi, d.wi = n, di, hi, wi
+    d.do_, d.ho, d.wo = grid
+    d.ks, d.stride = 3, 1
+    d.pad = (C.c_int32 * 3)(1, 1, 1)
+    d.wp, d.coutp = x0.data_ptr(), coutp
+    d.y, d.ldy, d.cstore = out.data_ptr(), act_ld(out), out.shape[4]
+    d.dy, d.hy, d.wy = out.shape[1:4]
+    d.os = 1
+    d.ooff = (C.c_int32 * 3)(0, 0, 0)
+    d.dtype = DT_FP8
+    d.q_amax_x = d.q_amax_w = x0.data_ptr()
+    return _lib.load().mi355_conv_plan_id(C.byref(d)) > 0
+
+
+def fp8_selftest(device) -> torch.Tensor:
+    out = torch.zeros(1024, dtype=torch.float32, device=device)
+    _lib.check(_lib.load().mi355_fp8_selftest(out.data_ptr(), _stream()), "fp8_selftest")
+    return out.view(32, 32)
 
 
 # ------------------------------------------------------------------------------ statistics / norm
