@@ -140,6 +140,28 @@ __device__ __forceinline__ uint4 ld_stream16(const char* p) {
 }
 
 // accumulator register i of lane half h holds D[row][col = lane & 31]
+// ---- LDS-DMA (buffer_load_dwordx4 ... lds) issued as inline assembly.
+// Through the builtin (__builtin_amdgcn_raw_ptr_buffer_load_lds) hipcc knows the instruction writes LDS and, with one
+// dynamic LDS array, cannot tell which part: it puts `s_waitcnt vmcnt(0)` in front of the NEXT ds_read, whatever
+// buffer that reads -- the copy of plane p + 1 then never overlaps the MFMAs of plane p (measured: the marching kernels
+// ran at the DMA's latency per plane).  As assembly the compiler does not track it; the kernel waits itself
+// (dma_wait_all) before the barrier that publishes the buffer.  The compiler's own vmcnt arithmetic for its other
+// memory instructions stays safe: untracked loads in flight only make a vmcnt(n) wait longer (loads return in order).
+typedef int dma_rsrc_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dma_rsrc_t dma_rsrc(const void* base, long long bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  dma_rsrc_t r = {(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+  return r;
+}
+// 64 lanes x 16 bytes -> LDS bytes [lds_addr + 16 * lane, + 16); source = base + soff + voff (per lane); a source offset
+// outside [0, bytes) yields zeros
+__device__ __forceinline__ void dma_lds_b128(const dma_rsrc_t rs, const void* lds_dst, const int voff, const int soff) {
+  const unsigned m = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)lds_dst;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(m), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
 static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

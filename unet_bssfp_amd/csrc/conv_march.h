@@ -101,8 +101,9 @@ __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, co
     vtab[i * 256] = ok ? ((gh * a.wi + gw) * a.ld0 * XB + q * 16) : (int)0x80000000;
   }
   const long long nvox = (long long)a.n * a.di * a.hi * a.wi;
-  const auto rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x0, 0, (int)(((nvox - 1) * a.ld0 + a.c0) * XB), 0x00020000);
-  const auto rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, 54 * a.coutp * 16 * XB, 0x00020000);
+  // (the copies are issued as inline assembly -- common.h, dma_lds_b128: through the builtin hipcc waits for ALL of them
+  //  before the next ds_read of any buffer, and the plane in flight never overlapped the MFMAs)
+  const dma_rsrc_t rsx = dma_rsrc(a.x0, ((nvox - 1) * a.ld0 + a.c0) * XB), rsw = dma_rsrc(a.wp, 54ll * a.coutp * 16 * XB);
   const int plane_stride = a.hi * a.wi * a.ld0 * XB;                  // bytes per input plane
   auto load_plane = [&](int p) __attribute__((always_inline)) {       // p: input plane index (outside [0, D): zeros)
     const bool pin = p >= 0 && p < a.di;
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, co
       // (bf16: the select form, which hipcc turns into short branches, keeps the table reads next to their DMA -- hoisted
       //  together as in the OR form they cost 10 registers this variant does not have)
       const int voff = F8 ? (vtab[i * 256] | kill) : (pin ? vtab[i * 256] : (int)0x80000000);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(dst + i * 4096), 16, voff, soff, 0, 0);
+      dma_lds_b128(rsx, dst + i * 4096, voff, soff);
     }
   };
   // ---- weights of this workgroup's 32 output channels, one 1-KB block = [lane half][row] x 16 B per fragment piece.  Row
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, co
       } else {                 // block j = chunk * 27 + tap: lane half h holds channels 8 h .. 8 h + 7 of the chunk
         src = ((j * a.coutp + co_base + wrow) * 2 + h) * 16;
       }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(wl + j * 1024), 16, src, 0, 0, 0);
+      dma_lds_b128(rsw, wl + j * 1024, src, 0);
     }
   }
   load_plane(d0 - 1);
@@ -331,6 +332,7 @@ __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, co
 #endif
     }
     pin_pipeline(3 * NG);
+    dma_wait_all();
     __syncthreads();
   };
   auto step = [&](int p, f32x16 (&s_m1)[4], f32x16 (&s_0)[4], f32x16 (&s_p1)[4]) __attribute__((always_inline)) {
@@ -349,9 +351,11 @@ __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, co
     }
     if (p >= d0 && p < d1) block(pl, s_0, 1, false);
     if (p + 1 < d1) block(pl, s_p1, 0, true);
-    __syncthreads();              // vmcnt(0): plane p + 1 has landed; every wave is done with plane p's buffer
+    dma_wait_all();               // plane p + 1 has landed (this wave's share) ...
+    __syncthreads();              // ... everybody's; every wave is done with plane p's buffer
   };
 
+  dma_wait_all();
   __syncthreads();                // weights and the first plane have landed
   // Two complete marches, never mixed (hipcc's register allocator cannot keep three 64-register accumulator sets in place
   // across a control-flow join of a straight-line step and a branchy one: it copied and spilled whole sets).
@@ -366,11 +370,13 @@ __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, co
     int p = d0 - 1;
     load_plane(p + 1);
     block(smem + (p & 1) * Cfg::PLANE, sa, 0, true);                  // input plane d0 - 1 -> output d0
+    dma_wait_all();
     __syncthreads();
     ++p;
     load_plane(p + 1);
     block(smem + (p & 1) * Cfg::PLANE, sa, 1, false);                 // input plane d0 -> outputs d0, d0 + 1
     block(smem + (p & 1) * Cfg::PLANE, sb, 0, true);
+    dma_wait_all();
     __syncthreads();
     ++p;
     for (int t3 = 0; t3 < (slen - 2) / 3; ++t3) {
@@ -383,6 +389,7 @@ __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, co
     block(smem + (p & 1) * Cfg::PLANE, sa, 2, false);
     store_plane(sa, p - 1);
     block(smem + (p & 1) * Cfg::PLANE, sb, 1, false);
+    dma_wait_all();
     __syncthreads();
     ++p;
     block(smem + (p & 1) * Cfg::PLANE, sb, 2, false);                 // p = d1

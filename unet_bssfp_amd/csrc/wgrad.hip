@@ -9,6 +9,7 @@
 // go to per-wave slabs and a second kernel reduces them in a fixed order (deterministic) and
 // scatters into the torch weight layout.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -402,6 +403,222 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradArgs a, i
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// wgrad_march_kernel: the 3x3x3 stride-1 weight gradient of the wide levels (W >= 32), marching along d.
+//
+// wgrad_bf16_kernel<3, 2, 4, 32> stages a 4 x 6 x 34 halo for 2 x 4 x 32 output positions (3.2x the tile's own
+// voxels) through registers, with a barrier on either side of the copy: 124 us for 32 -> 32 at 128^3, where the
+// MFMA work is 35 us and reading both operands once is 34 us.  Here a workgroup owns an 8 (h) x 32 (w) footprint
+// of one (ci-tile, co-tile) pair and walks a segment of output planes:
+//   * x planes (10 x 34 halo voxels x 32 channels) and g planes (8 x 32 x 32 channels) arrive by LDS-DMA
+//     (buffer_load_dwordx4 ... lds, 1 KB per instruction) TWO steps ahead of their use (one step of MFMAs, 1.6 us, is
+//     shorter than the loaded memory latency: with one step of look-ahead the kernel ran at 3.4 us per plane): a ring
+//     of 5 x planes -- output plane p pairs with x planes p - 1, p, p + 1 (kd = 0, 1, 2) while p + 2 and p + 3 are in
+//     flight -- and 3 g planes, 158 of the 160 KB; every x plane is read from memory once per workgroup (halo 1.33x in
+//     (h, w), (L + 2) / L along d), one barrier per plane, which waits for the OLDER of the two copies in flight only;
+//   * the 4 waves are (w-segment of 16 positions) x (half of the 9 (kd, kw) tap columns: 5 / 4).  A wave keeps the 8 g
+//     fragments of its segment (one per footprint row) in registers for the whole plane, and an x fragment of halo row y
+//     feeds the three taps kh = 0, 1, 2 (output rows y, y - 1, y - 2): ~1 ds_read_b64_tr_b16 per MFMA instead of 2.3;
+//   * the accumulators (15 / 12 taps x 16 registers) stay resident for the whole segment; at the end the two w-segment
+//     waves of a tap are added through LDS in a fixed order and ONE slab per workgroup is written (28 MB per layer
+//     instead of 57 MB); wgrad_reduce_kernel sums the slabs in order as before: bit-identical reruns.
+constexpr int kWmFH = 8, kWmFW = 32, kWmHR = kWmFH + 2, kWmHC = kWmFW + 2;
+constexpr int kWmXV = kWmHR * kWmHC;                  // 340 halo voxels per x plane
+constexpr int kWmXI = 24;                             // 1-KB DMA instructions per x plane, 6 per wave: 22 carry data, the last
+                                                      // two (out-of-range source: zeros) go to a 2-KB dump area
+constexpr int kWmXS = 22 * 1024;                      // bytes per x ring slot
+constexpr int kWmGI = 16, kWmGS = kWmGI * 1024;       // g plane: 256 voxels x 64 B
+constexpr int kWmXR = 5, kWmGR = 3;                   // ring depths
+constexpr int kWmLds = kWmXR * kWmXS + kWmGR * kWmGS + 2048;   // 160 KB
+constexpr int kWmPerStep = kWmXI / 4 + kWmGI / 4;     // DMA instructions per wave and step
+
+struct WMarchArgs { int seg_len, nseg, tiles_h, tiles_w; };
+
+// one plane of one wave: U0 = first (kd, kw) column, NU = number of columns (5 or 4)
+template <int U0, int NU>
+__device__ __forceinline__ void wm_plane(f32x16 (&acc)[5][3], const char* xs, const char* gp, const int p, const int seg_lane_off) {
+  bf16x8 gf[kWmFH];
+#pragma unroll
+  for (int sh = 0; sh < kWmFH; ++sh) gf[sh] = frag_tr(gp + sh * (kWmFW * 64));
+  const char* xb[NU];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) {
+    constexpr int dummy = 0; (void)dummy;
+    const int u = U0 + i, kd = u / 3, kw = u - kd * 3;
+    xb[i] = xs + ((unsigned)(p + kd) % kWmXR) * kWmXS + kw * 64 + seg_lane_off;      // x plane q sits in ring slot (q + 1) % 5
+  }
+  bf16x8 xf[2][NU];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) xf[0][i] = frag_tr(xb[i]);
+#pragma unroll
+  for (int y = 0; y < kWmHR; ++y) {
+    if (y + 1 < kWmHR) {
+#pragma unroll
+      for (int i = 0; i < NU; ++i) xf[(y + 1) & 1][i] = frag_tr(xb[i] + (y + 1) * (kWmHC * 64));
+    }
+#pragma unroll
+    for (int i = 0; i < NU; ++i)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int sh = y - kh;
+        if (sh >= 0 && sh < kWmFH) acc[i][kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[y & 1][i], gf[sh], acc[i][kh], 0, 0, 0);
+      }
+  }
+  // order: the g fragments and halo row 0, then per halo row its MFMAs with the next row's reads spread between them
+  // (one wave per SIMD: nothing else hides the LDS latency, and hipcc would sink every read next to its first use)
+  __builtin_amdgcn_sched_group_barrier(0x100, 2 * kWmFH + 2 * NU, 0);
+#pragma unroll
+  for (int y = 0; y < kWmHR; ++y) {
+    const int nm = (y == 0 || y == kWmHR - 1) ? 1 : ((y == 1 || y == kWmHR - 2) ? 2 : 3);
+    const int M = NU * nm, R = y + 1 < kWmHR ? 2 * NU : 0;
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      const int nr = R * (k + 1) / M - R * k / M;
+      if (nr == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      else if (nr == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      else if (nr == 3) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void wgrad_march_kernel(const WgradArgs a, const WMarchArgs m) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  char* const xs = smem;
+  char* const gsm = smem + kWmXR * kWmXS;
+  char* const dump = gsm + kWmGR * kWmGS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int seg = wave & 1, half = wave >> 1;
+  const int ci_base = blockIdx.y * 32, co_base = blockIdx.z * 32;
+  const bool first = ci_base < a.c0;
+  const char* xsrc = first ? a.x0 : a.x1;
+  const int ldx = first ? a.ld0 : a.ld1;
+  const int cix = first ? ci_base : ci_base - a.c0;
+  const int csrc = first ? a.c0 : a.c1;
+  const int cx_lim = csrc - cix, cg_lim = a.cg - co_base;
+
+  const int per_seg = m.tiles_h * m.tiles_w, per_sample = per_seg * m.nseg;
+  int t = blockIdx.x;
+  const int tn = t / per_sample;
+  t -= tn * per_sample;
+  const int sg = t / per_seg;
+  t -= sg * per_seg;
+  const int th_i = t / m.tiles_w, tw_i = t - th_i * m.tiles_w;
+  const int d0 = sg * m.seg_len, d1 = min(a.do_, d0 + m.seg_len);
+  const int h0 = th_i * kWmFH, w0 = tw_i * kWmFW;
+
+  // ---- DMA source offsets: instruction j = i * 4 + wave covers 16 voxels, lane = (voxel, 16-byte piece of 8 channels);
+  //      voxels outside the volume, channels past the source's width: out-of-range offset -> the DMA writes zeros
+  const int piece = lane & 3;
+  int xoff[kWmXI / 4], goff[kWmGI / 4];
+#pragma unroll
+  for (int i = 0; i < kWmXI / 4; ++i) {
+    const int v = (i * 4 + wave) * 16 + (lane >> 2);
+    const int y = v / kWmHC, col = v - y * kWmHC;
+    const int gh = h0 - 1 + y, gw = w0 - 1 + col;
+    const bool ok = v < kWmXV && gh >= 0 && gh < a.hi && gw >= 0 && gw < a.wi && piece * 8 < cx_lim;
+    xoff[i] = ok ? ((gh * a.wi + gw) * ldx + cix + piece * 8) * 2 : (int)0x80000000;
+  }
+#pragma unroll
+  for (int i = 0; i < kWmGI / 4; ++i) {
+    const int v = (i * 4 + wave) * 16 + (lane >> 2);
+    const int sh = v >> 5, sw = v & 31;
+    const int gh = h0 + sh, gw = w0 + sw;
+    const bool ok = gh < a.ho && gw < a.wo && piece * 8 < cg_lim;
+    goff[i] = ok ? ((gh * a.gw + gw) * a.ldg + co_base + piece * 8) * 2 : (int)0x80000000;
+  }
+  const long long nvx = (long long)a.n * a.di * a.hi * a.wi, nvg = (long long)a.n * a.gd * a.gh * a.gw;
+  const dma_rsrc_t rsx = dma_rsrc(xsrc, ((nvx - 1) * ldx + csrc) * 2), rsg = dma_rsrc(a.g, ((nvg - 1) * a.ldg + a.cg) * 2);
+  const int xplane = a.hi * a.wi * ldx * 2, gplane = a.gh * a.gw * a.ldg * 2;
+  auto load_x = [&](int q) __attribute__((always_inline)) {           // x plane q into ring slot (q + 1) % 5 (outside [0, D): zeros)
+    const bool pin = q >= 0 && q < a.di;
+    const int soff = pin ? (tn * a.di + q) * xplane : 0;
+    const int kill = pin ? 0 : (int)0x80000000;
+    char* dst = xs + ((unsigned)(q + 1) % kWmXR) * kWmXS + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < kWmXI / 4; ++i)
+      dma_lds_b128(rsx, (i == 5 && wave >= 2) ? dump + (wave - 2) * 1024 : dst + i * 4096, xoff[i] | kill, soff);
+  };
+  auto load_g = [&](int p) __attribute__((always_inline)) {           // g plane p into slot p % 3 (outside the segment: zeros, never read)
+    const bool pin = p < d1;
+    const int soff = pin ? (tn * a.gd + p) * gplane : 0;
+    const int kill = pin ? 0 : (int)0x80000000;
+    char* dst = gsm + ((unsigned)p % kWmGR) * kWmGS + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < kWmGI / 4; ++i) dma_lds_b128(rsg, dst + i * 4096, goff[i] | kill, soff);
+  };
+  load_x(d0 - 1);
+  load_x(d0);
+  load_x(d0 + 1);
+  load_x(d0 + 2);
+  load_g(d0);
+  load_g(d0 + 1);
+
+  f32x16 acc[5][3];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[i][k][j] = 0.f;
+  const int gi = lane & 15;
+  const int lane_off = (8 * h + (gi >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (gi & 3)) * 2;   // ds_read_b64_tr_b16 lane pattern (frag_tr)
+  const int seg_lane_off = seg * 16 * 64 + lane_off;
+  dma_wait_all();
+  __syncthreads();                                                    // the first planes have landed
+  // two whole marches (a wave's role never changes; a join of the two plane bodies inside the loop would make hipcc
+  // shuffle the 240 accumulator registers); every wave passes the same number of barriers
+  auto march = [&](auto u0c, auto nuc) __attribute__((always_inline)) {
+    for (int p = d0; p < d1; ++p) {
+#ifndef WM_DIAG_NO_DMA
+      load_x(p + 3);              // every step issues the same number of copies (past the segment: zeros into free slots),
+      load_g(p + 2);              // so that "all but the newest kWmPerStep" is the wait for the copies of the step before
+#endif
+      const char* gp = gsm + ((unsigned)p % kWmGR) * kWmGS + seg_lane_off;
+#ifndef WM_DIAG_NO_MMA
+      wm_plane<decltype(u0c)::value, decltype(nuc)::value>(acc, xs, gp, p, seg_lane_off);
+#endif
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kWmPerStep) : "memory");   // x plane p + 2, g plane p + 1 have landed (this wave's share) ...
+      __syncthreads();            // ... everybody's; and every wave is done with this plane's slots
+    }
+  };
+  if (half == 0) march(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+  else march(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
+  dma_wait_all();                 // the zero copies of the last steps must not land in the parking area
+  __syncthreads();
+  // ---- the two w-segment waves of a tap column: segment 1 parks its sums in LDS, segment 0 adds them (fixed order)
+  float* park = reinterpret_cast<float*>(smem) + (half ? 5 * 48 * 64 : 0) + lane;
+  const int nu = half ? 4 : 5, u0 = half ? 5 : 0;
+  if (seg == 1) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      if (i < nu)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) park[((i * 3 + k) * 16 + j) * 64] = acc[i][k][j];
+  }
+  __syncthreads();
+  if (seg == 0) {
+    float* sl = a.slab + (long long)blockIdx.x * 27 * a.cinp * a.coutp;
+    const int co = co_base + r;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      if (i < nu) {
+        const int u = u0 + i, kd = u / 3, kw = u - kd * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int tap = (kd * 3 + k) * 3 + kw;
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            sl[((long long)tap * a.cinp + ci_base + acc_row(j, h)) * a.coutp + co] = acc[i][k][j] + park[((i * 3 + k) * 16 + j) * 64];
+        }
+      }
+  }
+}
+
 // Transposed-conv (k2 s2) weight gradient, bf16: D[ci][cls * Cout + co] = sum_v x[v][ci] * g[2v + cls][co], one GEMM
 // with 8 * Cout columns.  `wgrad_bf16_kernel<1,..>` staged x once per 32-column tile: for 64->64 at 64^3 that is 16
 // re-reads of x and 2 of g (1.06 GB for 0.3 GB of operands, 256 us).  Here a workgroup owns NCO = 4 consecutive
@@ -486,7 +703,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_deconv_kernel(const WgradArgs a,
 }
 
 struct WPlan { int ks, tpw, tap_groups, ci_tiles, co_tiles, splits, cinp32, coutp32; long long rows;
-               bool fast, deconv4; int shape, tiles_d, tiles_h, tiles_w, ntiles, nslabs; };
+               bool fast, deconv4; int shape, tiles_d, tiles_h, tiles_w, ntiles, nslabs;
+               bool march; int seg_len, nseg; };
 
 const int kWTD[2] = {2, 2}, kWTH[2] = {4, 8}, kWTW[2] = {32, 16};
 
@@ -544,6 +762,28 @@ int wplan(const mi355_wgrad_desc* d, WPlan* p) {
     p->splits = (int)sp;
     p->nslabs = d->ks == 1 ? p->splits * 4 : p->splits;
   }
+  // marching kernel: 3x3x3, padding 1, same extents, wide rows; 32-bit byte offsets
+  p->march = false;
+  if (p->fast && !cls && d->ks == 3 && d->pad[0] == 1 && d->pad[1] == 1 && d->pad[2] == 1 && d->di == d->do_ && d->hi == d->ho &&
+      d->wi == d->wo && d->wo >= 32 && d->do_ >= 8 &&
+      (long long)d->n * d->di * d->hi * d->wi * std::max(d->ld0, std::max(d->ld1, d->ldg)) * 2 < (1ll << 31)) {
+    const int th = ceil_div(d->ho, kWmFH), tw = ceil_div(d->wo, kWmFW);
+    const long long base = (long long)d->n * th * tw * p->ci_tiles * p->co_tiles;
+    // segments: whole rounds of 256 workgroups (one per CU), cost = rounds x (planes per segment + pipeline fill)
+    long long best = -1; int best_ns = 1;
+    for (int ns = 1; ns <= d->do_ / 4; ++ns) {
+      const int L = ceil_div(d->do_, ns);
+      if ((long long)(ns - 1) * L >= d->do_) continue;
+      const long long wgs = base * ns, cost = ((wgs + 255) / 256) * (L + 3);
+      if ((long long)ns * d->n * th * tw * slab_bytes > (256ll << 20)) break;
+      if (best < 0 || cost < best) { best = cost; best_ns = ns; }
+    }
+    p->march = true;
+    p->nseg = best_ns;
+    p->seg_len = ceil_div(d->do_, best_ns);
+    p->tiles_h = th; p->tiles_w = tw;
+    p->nslabs = d->n * th * tw * best_ns;
+  }
   return MI355_OK;
 }
 
@@ -588,7 +828,12 @@ extern "C" int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream) {
   a.slab = d->workspace; a.cinp = p.cinp32; a.coutp = p.coutp32;
   a.splits = p.splits; a.tap_groups = p.tap_groups; a.rows = p.rows;
   a.g_cls_cout = d->g_cls_cout;
-  if (p.fast && p.deconv4) {
+  if (p.march) {
+    const WMarchArgs m{p.seg_len, p.nseg, p.tiles_h, p.tiles_w};
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)wgrad_march_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWmLds); attr = true; }
+    wgrad_march_kernel<<<dim3(p.nslabs, p.ci_tiles, p.co_tiles), dim3(256), kWmLds, st>>>(a, m);
+  } else if (p.fast && p.deconv4) {
     const dim3 grid(p.splits, p.ci_tiles, p.co_tiles / kDeconvNco);
     wgrad_deconv_kernel<<<grid, dim3(256), (1 + kDeconvNco) * 256 * 64, st>>>(a, p.tiles_d, p.tiles_h, p.tiles_w, p.ntiles);
   } else if (p.fast) {
