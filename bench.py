@@ -238,7 +238,8 @@ class FreshBatches:
         for (_, t), s in zip(self.keys, self.staging):
             t.copy_(s, non_blocking=True)
         self.consumed.record(cur)
-        self.prefetch()                                          # next batch crosses PCIe under this step
+        # the caller launches the step FIRST and then calls prefetch(): enqueueing a 250 MB host-to-device copy can hold
+        # the CPU thread for milliseconds, which must pass while the GPU is busy with the step, not in front of it
 
 
 def main():
@@ -306,6 +307,8 @@ def main():
             if fresh is not None:
                 fresh.swap_in()
             gstep()
+            if fresh is not None:
+                fresh.prefetch()                                 # next batch crosses PCIe under this step
         mode = "hipgraph"
     else:
         if world > 1:

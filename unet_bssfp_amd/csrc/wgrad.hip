@@ -416,11 +416,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradArgs a, i
 //     of 5 x planes -- output plane p pairs with x planes p - 1, p, p + 1 (kd = 0, 1, 2) while p + 2 and p + 3 are in
 //     flight -- and 3 g planes, 158 of the 160 KB; every x plane is read from memory once per workgroup (halo 1.33x in
 //     (h, w), (L + 2) / L along d), one barrier per plane, which waits for the OLDER of the two copies in flight only;
-//   * the 4 waves are (w-segment of 16 positions) x (half of the 9 (kd, kw) tap columns: 5 / 4).  A wave keeps the 8 g
+//   * the 4 waves are (w-segment of 16 positions) x (half of the 9 (kd, kw) tap columns: 4 whole columns each and the
+//     footprint's upper / lower rows of the ninth, 108 MFMAs per plane for every wave).  A wave keeps the 8 g
 //     fragments of its segment (one per footprint row) in registers for the whole plane, and an x fragment of halo row y
 //     feeds the three taps kh = 0, 1, 2 (output rows y, y - 1, y - 2): ~1 ds_read_b64_tr_b16 per MFMA instead of 2.3;
-//   * the accumulators (15 / 12 taps x 16 registers) stay resident for the whole segment; at the end the two w-segment
-//     waves of a tap are added through LDS in a fixed order and ONE slab per workgroup is written (28 MB per layer
+//   * the accumulators (15 taps x 16 registers) stay resident for the whole segment; at the end the waves that hold
+//     parts of a tap are added through LDS in a fixed order and ONE slab per workgroup is written (28 MB per layer
 //     instead of 57 MB); wgrad_reduce_kernel sums the slabs in order as before: bit-identical reruns.
 constexpr int kWmFH = 8, kWmFW = 32, kWmHR = kWmFH + 2, kWmHC = kWmFW + 2;
 constexpr int kWmXV = kWmHR * kWmHC;                  // 340 halo voxels per x plane
@@ -432,45 +433,61 @@ constexpr int kWmXR = 5, kWmGR = 3;                   // ring depths
 constexpr int kWmLds = kWmXR * kWmXS + kWmGR * kWmGS + 2048;   // 160 KB
 constexpr int kWmPerStep = kWmXI / 4 + kWmGI / 4;     // DMA instructions per wave and step
 
-struct WMarchArgs { int seg_len, nseg, tiles_h, tiles_w; };
+struct WMarchArgs { int seg_len, nseg, tiles_h, tiles_w, nslabs, ci_tiles, co_tiles; };
 
-// one plane of one wave: U0 = first (kd, kw) column, NU = number of columns (5 or 4)
-template <int U0, int NU>
+// Tap columns of a wave: HALF 0 owns (kd, kw) columns 0..3, HALF 1 columns 5..8 (local index 0..3), and both own
+// column 4 (local index 4) for half of the footprint rows each -- 4.5 columns = 108 MFMAs per plane for every wave.
+constexpr int wm_unit(int half, int i) { return i == 4 ? 4 : (half ? 5 + i : i); }
+constexpr bool wm_valid(int half, int i, int y, int kh) {            // does halo row y feed tap kh of local column i?
+  const int sh = y - kh, lo = (i == 4 && half == 1) ? kWmFH / 2 : 0, hi = (i == 4 && half == 0) ? kWmFH / 2 : kWmFH;
+  return sh >= lo && sh < hi;
+}
+constexpr bool wm_need(int half, int i, int y) { return y < kWmHR && (wm_valid(half, i, y, 0) || wm_valid(half, i, y, 1) || wm_valid(half, i, y, 2)); }
+constexpr int wm_row_mfmas(int half, int y) {
+  int n = 0;
+  for (int i = 0; i < 5; ++i) for (int kh = 0; kh < 3; ++kh) n += wm_valid(half, i, y, kh) ? 1 : 0;
+  return n;
+}
+constexpr int wm_row_reads(int half, int y) {
+  int n = 0;
+  for (int i = 0; i < 5; ++i) n += wm_need(half, i, y) ? 2 : 0;
+  return n;
+}
+
+// one plane of one wave
+template <int HALF>
 __device__ __forceinline__ void wm_plane(f32x16 (&acc)[5][3], const char* xs, const char* gp, const int p, const int seg_lane_off) {
   bf16x8 gf[kWmFH];
 #pragma unroll
   for (int sh = 0; sh < kWmFH; ++sh) gf[sh] = frag_tr(gp + sh * (kWmFW * 64));
-  const char* xb[NU];
+  const char* xb[5];
 #pragma unroll
-  for (int i = 0; i < NU; ++i) {
-    constexpr int dummy = 0; (void)dummy;
-    const int u = U0 + i, kd = u / 3, kw = u - kd * 3;
+  for (int i = 0; i < 5; ++i) {
+    const int u = wm_unit(HALF, i), kd = u / 3, kw = u - kd * 3;
     xb[i] = xs + ((unsigned)(p + kd) % kWmXR) * kWmXS + kw * 64 + seg_lane_off;      // x plane q sits in ring slot (q + 1) % 5
   }
-  bf16x8 xf[2][NU];
+  bf16x8 xf[2][5];
 #pragma unroll
-  for (int i = 0; i < NU; ++i) xf[0][i] = frag_tr(xb[i]);
+  for (int i = 0; i < 5; ++i)
+    if (wm_need(HALF, i, 0)) xf[0][i] = frag_tr(xb[i]);
 #pragma unroll
   for (int y = 0; y < kWmHR; ++y) {
-    if (y + 1 < kWmHR) {
 #pragma unroll
-      for (int i = 0; i < NU; ++i) xf[(y + 1) & 1][i] = frag_tr(xb[i] + (y + 1) * (kWmHC * 64));
-    }
+    for (int i = 0; i < 5; ++i)
+      if (wm_need(HALF, i, y + 1)) xf[(y + 1) & 1][i] = frag_tr(xb[i] + (y + 1) * (kWmHC * 64));
 #pragma unroll
-    for (int i = 0; i < NU; ++i)
+    for (int i = 0; i < 5; ++i)
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int sh = y - kh;
-        if (sh >= 0 && sh < kWmFH) acc[i][kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[y & 1][i], gf[sh], acc[i][kh], 0, 0, 0);
-      }
+      for (int kh = 0; kh < 3; ++kh)
+        if (wm_valid(HALF, i, y, kh))
+          acc[i][kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[y & 1][i], gf[y - kh], acc[i][kh], 0, 0, 0);
   }
   // order: the g fragments and halo row 0, then per halo row its MFMAs with the next row's reads spread between them
   // (one wave per SIMD: nothing else hides the LDS latency, and hipcc would sink every read next to its first use)
-  __builtin_amdgcn_sched_group_barrier(0x100, 2 * kWmFH + 2 * NU, 0);
+  __builtin_amdgcn_sched_group_barrier(0x100, 2 * kWmFH + wm_row_reads(HALF, 0), 0);
 #pragma unroll
   for (int y = 0; y < kWmHR; ++y) {
-    const int nm = (y == 0 || y == kWmHR - 1) ? 1 : ((y == 1 || y == kWmHR - 2) ? 2 : 3);
-    const int M = NU * nm, R = y + 1 < kWmHR ? 2 * NU : 0;
+    const int M = wm_row_mfmas(HALF, y), R = wm_row_reads(HALF, y + 1);
 #pragma unroll
     for (int k = 0; k < M; ++k) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -491,7 +508,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_march_kernel(const WgradArgs a, 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int seg = wave & 1, half = wave >> 1;
-  const int ci_base = blockIdx.y * 32, co_base = blockIdx.z * 32;
+  // workgroup -> (slab, ci tile, co tile): the tile pairs of one slab (same g planes / same x voxels) are neighbours in
+  // dispatch order ON THE SAME XCD (workgroup ids go round-robin over the 8 XCDs), so that what they share is read from
+  // memory once and from that XCD's L2 afterwards (96 -> 32: three ci tiles re-read the same g)
+  const int tpairs = m.ci_tiles * m.co_tiles;
+  const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+  const int slab = (kq / tpairs) * 8 + xcd, pair = kq % tpairs;
+  if (slab >= m.nslabs) return;                                       // (whole workgroup; grid rounded up to 8 slabs)
+  const int ci_base = (pair % m.ci_tiles) * 32, co_base = (pair / m.ci_tiles) * 32;
   const bool first = ci_base < a.c0;
   const char* xsrc = first ? a.x0 : a.x1;
   const int ldx = first ? a.ld0 : a.ld1;
@@ -500,7 +524,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_march_kernel(const WgradArgs a, 
   const int cx_lim = csrc - cix, cg_lim = a.cg - co_base;
 
   const int per_seg = m.tiles_h * m.tiles_w, per_sample = per_seg * m.nseg;
-  int t = blockIdx.x;
+  int t = slab;
   const int tn = t / per_sample;
   t -= tn * per_sample;
   const int sg = t / per_seg;
@@ -570,7 +594,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_march_kernel(const WgradArgs a, 
   __syncthreads();                                                    // the first planes have landed
   // two whole marches (a wave's role never changes; a join of the two plane bodies inside the loop would make hipcc
   // shuffle the 240 accumulator registers); every wave passes the same number of barriers
-  auto march = [&](auto u0c, auto nuc) __attribute__((always_inline)) {
+  auto march = [&](auto halfc) __attribute__((always_inline)) {
     for (int p = d0; p < d1; ++p) {
 #ifndef WM_DIAG_NO_DMA
       load_x(p + 3);              // every step issues the same number of copies (past the segment: zeros into free slots),
@@ -578,44 +602,56 @@ __global__ __launch_bounds__(256, 1) void wgrad_march_kernel(const WgradArgs a, 
 #endif
       const char* gp = gsm + ((unsigned)p % kWmGR) * kWmGS + seg_lane_off;
 #ifndef WM_DIAG_NO_MMA
-      wm_plane<decltype(u0c)::value, decltype(nuc)::value>(acc, xs, gp, p, seg_lane_off);
+      wm_plane<decltype(halfc)::value>(acc, xs, gp, p, seg_lane_off);
 #endif
+#ifndef WM_DIAG_NO_WAIT
       asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kWmPerStep) : "memory");   // x plane p + 2, g plane p + 1 have landed (this wave's share) ...
+#endif
+#ifndef WM_DIAG_NO_BARRIER
       __syncthreads();            // ... everybody's; and every wave is done with this plane's slots
+#endif
     }
   };
-  if (half == 0) march(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
-  else march(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
+  if (half == 0) march(std::integral_constant<int, 0>{});
+  else march(std::integral_constant<int, 1>{});
   dma_wait_all();                 // the zero copies of the last steps must not land in the parking area
   __syncthreads();
-  // ---- the two w-segment waves of a tap column: segment 1 parks its sums in LDS, segment 0 adds them (fixed order)
-  float* park = reinterpret_cast<float*>(smem) + (half ? 5 * 48 * 64 : 0) + lane;
-  const int nu = half ? 4 : 5, u0 = half ? 5 : 0;
+  // ---- partial sums of a tap live in two waves (the two w-segments), those of the shared column 4 in all four: everybody
+  //      but the writer parks them in LDS, the writer adds them in a fixed order (bit-identical reruns) and writes the slab
+  float* const parkA = reinterpret_cast<float*>(smem) + lane;         // [half][i (5)][kh][j][lane]: the segment-1 waves
+  float* const parkB = parkA + 2 * 5 * 48 * 64;                       // [kh][j][lane]: column 4 of (segment 0, half 1)
   if (seg == 1) {
 #pragma unroll
     for (int i = 0; i < 5; ++i)
-      if (i < nu)
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+      for (int k = 0; k < 3; ++k)
 #pragma unroll
-          for (int j = 0; j < 16; ++j) park[((i * 3 + k) * 16 + j) * 64] = acc[i][k][j];
+        for (int j = 0; j < 16; ++j) parkA[(((half * 5 + i) * 3 + k) * 16 + j) * 64] = acc[i][k][j];
+  } else if (half == 1) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) parkB[(k * 16 + j) * 64] = acc[4][k][j];
   }
   __syncthreads();
   if (seg == 0) {
-    float* sl = a.slab + (long long)blockIdx.x * 27 * a.cinp * a.coutp;
+    float* sl = a.slab + (long long)slab * 27 * a.cinp * a.coutp;
     const int co = co_base + r;
 #pragma unroll
-    for (int i = 0; i < 5; ++i)
-      if (i < nu) {
-        const int u = u0 + i, kd = u / 3, kw = u - kd * 3;
+    for (int i = 0; i < 5; ++i) {
+      if (i == 4 && half == 1) break;                                 // column 4 is written by (segment 0, half 0)
+      const int u = i == 4 ? 4 : (half ? 5 + i : i), kd = u / 3, kw = u - kd * 3;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const int tap = (kd * 3 + k) * 3 + kw;
+      for (int k = 0; k < 3; ++k) {
+        const int tap = (kd * 3 + k) * 3 + kw;
 #pragma unroll
-          for (int j = 0; j < 16; ++j)
-            sl[((long long)tap * a.cinp + ci_base + acc_row(j, h)) * a.coutp + co] = acc[i][k][j] + park[((i * 3 + k) * 16 + j) * 64];
+        for (int j = 0; j < 16; ++j) {
+          float v = acc[i][k][j] + parkA[(((half * 5 + i) * 3 + k) * 16 + j) * 64];
+          if (i == 4) v = (v + parkB[(k * 16 + j) * 64]) + parkA[(((1 * 5 + 4) * 3 + k) * 16 + j) * 64];
+          sl[((long long)tap * a.cinp + ci_base + acc_row(j, h)) * a.coutp + co] = v;
         }
       }
+    }
   }
 }
 
@@ -829,10 +865,10 @@ extern "C" int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream) {
   a.splits = p.splits; a.tap_groups = p.tap_groups; a.rows = p.rows;
   a.g_cls_cout = d->g_cls_cout;
   if (p.march) {
-    const WMarchArgs m{p.seg_len, p.nseg, p.tiles_h, p.tiles_w};
+    const WMarchArgs m{p.seg_len, p.nseg, p.tiles_h, p.tiles_w, p.nslabs, p.ci_tiles, p.co_tiles};
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)wgrad_march_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWmLds); attr = true; }
-    wgrad_march_kernel<<<dim3(p.nslabs, p.ci_tiles, p.co_tiles), dim3(256), kWmLds, st>>>(a, m);
+    wgrad_march_kernel<<<dim3(((p.nslabs + 7) / 8) * 8 * p.ci_tiles * p.co_tiles), dim3(256), kWmLds, st>>>(a, m);
   } else if (p.fast && p.deconv4) {
     const dim3 grid(p.splits, p.ci_tiles, p.co_tiles / kDeconvNco);
     wgrad_deconv_kernel<<<grid, dim3(256), (1 + kDeconvNco) * 256 * 64, st>>>(a, p.tiles_d, p.tiles_h, p.tiles_w, p.ntiles);
