@@ -257,8 +257,9 @@ int mi355_colsum_finalize_into(const float* part, int32_t parts, int32_t c, floa
 
 /* ------------------------------------------------------------------------------------------
  * MaxPool3d(kernel_size=2) -- MONAI BasicUNet `Down` (call site src/model.py:22-28).
- * Even extents only.  Backward routes the gradient to the first maximum in (d,h,w) scan order
- * (torch CPU semantics) and writes zeros elsewhere (dx fully written).
+ * Extents >= 2; an odd extent is floored (the last plane / row / column belongs to no window).  Backward routes
+ * the gradient to the first maximum in (d,h,w) scan order (torch CPU semantics) and writes zeros elsewhere (dx
+ * fully written, the planes outside every window included).
  * ---------------------------------------------------------------------------------------- */
 int mi355_maxpool2_fwd(const void* x, int32_t ldx, void* y, int32_t ldy, int32_t n, int32_t c,
                        int32_t d, int32_t h, int32_t w, int32_t dtype, void* stream);

@@ -152,6 +152,37 @@ def test_generator_matches_oracle_with_other_seed_and_batch(hip):
     torch.testing.assert_close(y, y_ref, rtol=2e-3, atol=2e-4)
 
 
+def test_generator_odd_skip_extents_replicate_pad(hip):
+    """MONAI UpCat's is_pad branch: extents that are not divisible by 16 leave odd levels (40 -> 20 -> 10 -> 5 -> 2; the
+    up-sampled 4 meets a skip of 5).  Forward AND parameter gradients against the oracle (oracle/unet_ref.py:236-243), f32."""
+    from unet_bssfp_amd import Generator
+    torch.manual_seed(7)
+    g = Generator("bssfp", dropout=0.0)
+    ref = R.RefGenerator("bssfp", dropout=0.0).train()
+    ref.load_state_dict(g.state_dict())
+    x, y = R.synthetic_batch(1, (40, 24, 56), seed=12)
+    y_ref = ref(x)
+    (y_ref - y).abs().mean().backward()
+    g = g.to(DEV).train()
+    y_hip = g(x.to(DEV))
+    (y_hip - y.to(DEV)).abs().mean().backward()
+    assert (y_hip.detach().cpu() - y_ref.detach()).abs().mean().item() <= 1e-4
+    torch.testing.assert_close(y_hip.detach().cpu(), y_ref.detach(), rtol=2e-3, atol=2e-4)
+    refp = dict(ref.named_parameters())
+    for name, p in g.named_parameters():
+        if refp[name].grad is None:                                   # the other modalities' input heads
+            assert p.grad is None, name
+            continue
+        gr, gh = refp[name].grad, p.grad.cpu()
+        if name.endswith(".conv.bias"):
+            # a bias in front of a normalisation has a mathematically zero gradient: the oracle holds 1e-8 .. 1e-6 of
+            # round-off, this path (which never adds the bias before the statistics) exactly 0
+            assert float(gh.abs().max()) <= 1e-5, name
+            continue
+        err = (gh - gr).norm()                                        # 5e-3: the bound of the golden-vector test above
+        assert err <= 5e-3 * gr.norm() + 1e-7, (name, float(err), float(gr.norm()))
+
+
 def test_reference_construction_site_drop_in(hip):
     """A reference-style Generator.forward (src/model.py:36-39) chaining the PUBLIC forwards of our
     DownSampleConv and BasicUNet gives the same result as our fused Generator (zero-copy hand-off)."""

@@ -325,10 +325,25 @@ def test_maxpool_fwd_bwd(hip, dtype):
     assert torch.equal(from_act(xd.grad, 32), x_cpu.grad)
 
 
-def test_maxpool_odd_extent_is_rejected(hip):
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_maxpool_odd_extents_floor(hip, dtype):
+    """MaxPool3d(2) floors odd extents (the levels MONAI's replicate-pad branch exists for): the last plane / row / column is
+    in no window, its gradient is zero -- and dx is still fully written (no stale memory)."""
+    from unet_bssfp_amd import functional as Fn
+    g = torch.Generator().manual_seed(12)
+    x = q(torch.randn(2, 16, 5, 7, 9, generator=g), dtype)
+    x_cpu = x.clone().requires_grad_(True)
+    y_ref = F.max_pool3d(x_cpu, 2)
+    gy = q(torch.rand(y_ref.shape, generator=g), dtype)
+    y_ref.backward(gy)
+    xd = to_act(x, dtype).requires_grad_(True)
+    y = Fn.MaxPoolFn.apply(xd)
+    assert torch.equal(from_act(y, 16), y_ref.detach())
+    y.backward(to_act(gy, dtype))
+    assert torch.equal(from_act(xd.grad, 16), x_cpu.grad)
     from unet_bssfp_amd import _lib
     with pytest.raises(_lib.Mi355Error):
-        _ops().maxpool2_fwd(to_act(torch.rand(1, 16, 3, 4, 4), torch.float32))
+        _ops().maxpool2_fwd(to_act(torch.rand(1, 16, 1, 4, 4), torch.float32))      # an extent below the window
 
 
 def test_l1_loss_fwd_bwd(hip):

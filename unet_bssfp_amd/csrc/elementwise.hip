@@ -489,7 +489,9 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
   m.store(y + o * ldy + piece * EPV);
 }
 
-template <typename T>
+// ODD: some extent is odd -- MaxPool3d(2) floors, the last plane / row / column belongs to no window: its gradient is zero
+// (+ add); the thread of the last window along such an axis writes it.
+template <typename T, bool ODD>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ y,
                                                            int ldy, const T* __restrict__ dy, int lddy,
                                                            T* __restrict__ dx, int lddx, int c, int d, int h, int w,
@@ -510,18 +512,22 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
   bool taken[EPV];
 #pragma unroll
   for (int j = 0; j < EPV; ++j) taken[j] = false;
+  constexpr int KN = ODD ? 3 : 2;
+  const bool xd = ODD && od == od_ - 1 && (d & 1), xh = ODD && oh == oh_ - 1 && (h & 1), xw = ODD && ow == ow_ - 1 && (w & 1);
 #pragma unroll
-  for (int kd = 0; kd < 2; ++kd)
+  for (int kd = 0; kd < KN; ++kd)
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
+    for (int kh = 0; kh < KN; ++kh)
 #pragma unroll
-      for (int kw = 0; kw < 2; ++kw) {
+      for (int kw = 0; kw < KN; ++kw) {
+        const bool inwin = kd < 2 && kh < 2 && kw < 2;
+        if (!inwin && ((kd == 2 && !xd) || (kh == 2 && !xh) || (kw == 2 && !xw))) continue;
         const long long vox = (((long long)n * d + 2 * od + kd) * h + 2 * oh + kh) * w + 2 * ow + kw;
         Vec16<T> v, outv;
-        v.load(x + vox * ldx + piece * EPV);
+        if (inwin) v.load(x + vox * ldx + piece * EPV);
 #pragma unroll
         for (int j = 0; j < EPV; ++j) {
-          const bool hit = !taken[j] && (v.f[j] == m.f[j] || v.f[j] != v.f[j]);
+          const bool hit = inwin && !taken[j] && (v.f[j] == m.f[j] || v.f[j] != v.f[j]);
           outv.f[j] = hit ? g.f[j] : 0.f;
           taken[j] = taken[j] || hit;
         }
@@ -1083,7 +1089,7 @@ int mi355_normact_bwd_apply(const mi355_normact_desc* d, void* stream) {
 int mi355_maxpool2_fwd(const void* x, int32_t ldx, void* y, int32_t ldy, int32_t n, int32_t c, int32_t d, int32_t h,
                        int32_t w, int32_t dtype, void* stream) {
   MI355_REQUIRE(x && y && n > 0, "maxpool_fwd: bad argument");
-  MI355_REQUIRE(d % 2 == 0 && h % 2 == 0 && w % 2 == 0 && d > 0 && h > 0 && w > 0, "maxpool: extents must be even (%d,%d,%d)", d, h, w);
+  MI355_REQUIRE(d >= 2 && h >= 2 && w >= 2, "maxpool: extents must be >= 2 (%d,%d,%d)", d, h, w);   // odd: floor, as MaxPool3d(2)
   int rc = check_rows(c, ldx, dtype, "maxpool_fwd");
   if (rc) return rc;
   rc = check_rows(c, ldy, dtype, "maxpool_fwd");
@@ -1102,7 +1108,8 @@ static int maxpool_bwd_impl(const void* x, int32_t ldx, const void* y, int32_t l
                             int32_t lddx, const void* add, int32_t ldadd, int32_t n, int32_t c, int32_t d, int32_t h,
                             int32_t w, int32_t dtype, void* stream) {
   MI355_REQUIRE(x && y && dy && dx && n > 0, "maxpool_bwd: bad argument");
-  MI355_REQUIRE(d % 2 == 0 && h % 2 == 0 && w % 2 == 0 && d > 0 && h > 0 && w > 0, "maxpool: extents must be even");
+  MI355_REQUIRE(d >= 2 && h >= 2 && w >= 2, "maxpool: extents must be >= 2 (%d,%d,%d)", d, h, w);
+  const bool odd = (d | h | w) & 1;
   int rc = check_rows(c, ldx, dtype, "maxpool_bwd");
   if (rc) return rc;
   if ((rc = check_rows(c, ldy, dtype, "maxpool_bwd"))) return rc;
@@ -1112,10 +1119,10 @@ static int maxpool_bwd_impl(const void* x, int32_t ldx, const void* y, int32_t l
   const int epv = dtype == MI355_DT_F32 ? 4 : 8;
   const long long total = (long long)n * (d / 2) * (h / 2) * (w / 2) * (c / epv);
   dim3 grid((unsigned)((total + 255) / 256));
-  if (dtype == MI355_DT_F32)
-    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (const float*)y, ldy, (const float*)dy, lddy, (float*)dx, lddx, c, d, h, w, total, (const float*)add, ldadd);
-  else
-    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)y, ldy, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, c, d, h, w, total, (const bf16_t*)add, ldadd);
+#define MP_BWD(T, O) hipLaunchKernelGGL((maxpool_bwd_kernel<T, O>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, (const T*)y, ldy, (const T*)dy, lddy, (T*)dx, lddx, c, d, h, w, total, (const T*)add, ldadd)
+  if (dtype == MI355_DT_F32) { if (odd) MP_BWD(float, true); else MP_BWD(float, false); }
+  else { if (odd) MP_BWD(bf16_t, true); else MP_BWD(bf16_t, false); }
+#undef MP_BWD
   return mi355_check_launch("maxpool_bwd");
 }
 

@@ -310,8 +310,15 @@ class UpCat(_Mi355Module):
     def forward_act(self, x, x_e):
         x_0 = self.upsample.deconv.forward_act(x)
         if x_0.shape[1:4] != x_e.shape[1:4]:
-            raise NotImplementedError("odd skip extents (MONAI replicate-pad branch) are not implemented: "
-                                      "spatial sizes must be divisible by 16")
+            # MONAI UpCat (is_pad): a level whose extent is odd loses its last plane in MaxPool3d(2); the up-sampled map is
+            # then one short of the skip and is replicate-padded by one at the END of every such axis.  Never taken by
+            # the reference's own volumes (src/model.py:109-110 asserts divisibility by 16); plain tensor ops, autograd
+            # handles the gradient (the padded plane's gradient is added to the last real one).
+            for ax in (1, 2, 3):
+                if x_0.shape[ax] + 1 == x_e.shape[ax]:
+                    x_0 = torch.cat([x_0, x_0.narrow(ax, x_0.shape[ax] - 1, 1)], ax)
+            if x_0.shape[1:4] != x_e.shape[1:4]:
+                raise ValueError(f"skip {tuple(x_e.shape[1:4])} and up-sampled map {tuple(x_0.shape[1:4])} differ by more than one")
         return self.convs.forward_act(x_e, x_0)        # virtual cat([x_e, x_0], 1): skip first
 
 
@@ -347,10 +354,10 @@ class BasicUNet(_Mi355Module):
         self.final_conv = Conv3d(f[5], out_channels, kernel_size=1)
 
     def forward_act(self, x):
-        for e in x.shape[1:4]:
-            if e % 16 != 0 or e // 16 < 2:
-                raise ValueError(f"spatial extents must be divisible by 16 and >= 32 (InstanceNorm needs > 1 "
-                                 f"element at the bottom level), got {tuple(x.shape[1:4])}")
+        d, h, w = x.shape[1:4]
+        if min(d, h, w) < 16 or (d >> 4) * (h >> 4) * (w >> 4) < 2:
+            raise ValueError(f"four 2x poolings need extents >= 16, and InstanceNorm more than one element at the bottom "
+                             f"level; got {tuple(x.shape[1:4])}")
         x0 = self.conv_0.forward_act(x)
         s0, x1 = self.down_1.forward_skip(x0)
         s1, x2 = self.down_2.forward_skip(x1)
