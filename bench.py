@@ -81,7 +81,8 @@ class Probe:
 
     def __init__(self):
         self.enabled = False
-        self.conv = {}          # plan id -> [events, flops]
+        self.conv = {}          # (plan id, operand dtype) -> [events, flops]
+        self.conv_bytes = {}    # same key -> algorithmic bytes (input read once + output written once, stored widths)
         self.norm = {}          # "fwd" / "bwd" -> [events, algorithmic bytes]
 
     def _bracket(self, store, key, work):
@@ -96,7 +97,12 @@ class Probe:
         if not self.enabled:
             return None
         cin, cout = real if real is not None else (d.c0 + d.c1, d.cstore)
-        return self._bracket(self.conv, (plan_id, int(d.dtype)), 2.0 * cin * cout * (d.ks ** 3) * d.n * d.do_ * d.ho * d.wo)
+        key = (plan_id, int(d.dtype))
+        eb_in = 1 if int(d.dtype) == 3 else (4 if int(d.dtype) == 0 else 2)     # e4m3 operands, bf16 / f32 otherwise
+        eb_out = 4 if int(d.dtype) == 0 else 2
+        self.conv_bytes[key] = self.conv_bytes.get(key, 0.0) + float(d.n) * (
+            (d.c0 + d.c1) * d.di * d.hi * d.wi * eb_in + d.cstore * d.do_ * d.ho * d.wo * eb_out)
+        return self._bracket(self.conv, key, 2.0 * cin * cout * (d.ks ** 3) * d.n * d.do_ * d.ho * d.wo)
 
     def norm_probe(self, kind, c_real, rows, elem_bytes):
         if not self.enabled:
@@ -395,6 +401,8 @@ def main():
             traffic, tinfo = profiled_traffic(name, a.dtype, a.size, a.workload, a.batch)
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
                                "frac": ach / PEAK_TFLOPS[a.dtype], "traffic": traffic, "traffic_source": tinfo,
+                               "algorithmic_bytes": probe.conv_bytes.get((pid, dcode), 0.0) / max(1, s["launches"]),
+                               "traffic_over_algorithmic": (traffic / (probe.conv_bytes.get((pid, dcode), 0.0) / max(1, s["launches"]))) if traffic else None,
                                "kernel": name, "launches": s["launches"], "avg_launch_ms": s["avg_ms"],
                                "share_of_conv_time": s["total_ms"] / max(1e-9, sum(Probe._sum(e)["total_ms"] for e in probe.conv.values())),
                                "measured": probe_mode}
