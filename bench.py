@@ -51,7 +51,7 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "fp8": 5000.0}
 HBM_PEAK_GBS = 8000.0
 # plan id = 10000*ks + 1000*halo + 100*tile_shape + 10*voxel_subtiles_per_wave + cout_subtiles_per_wave
 PLAN_NAMES = {32041: "conv_march_kernel", 31941: "conv_ru_kernel<1>", 31942: "conv_ru_kernel<2>", 31021: "conv_halo_kernel<float,3,2,4,32,1>",
-              31022: "conv_halo_kernel<float,3,2,4,32,2>"}
+              31022: "conv_halo_kernel<float,3,2,4,32,2>", 31411: "conv_halo_kernel<bf16_t,3,2,4,16,1,4>"}
 KERNEL_SOURCES = ("conv_march.h", "conv_kernels.h", "conv_common.h", "conv_api.hip", "common.h")
 
 
@@ -81,6 +81,7 @@ class Probe:
 
     def __init__(self):
         self.enabled = False
+        self.overhead_ms = 0.0  # what an empty event bracket reads (subtracted per launch): see calibrate()
         self.conv = {}          # (plan id, operand dtype) -> [events, flops]
         self.conv_bytes = {}    # same key -> algorithmic bytes (input read once + output written once, stored widths)
         self.norm = {}          # "fwd" / "bwd" -> [events, algorithmic bytes]
@@ -110,9 +111,20 @@ class Probe:
         passes = 2 if kind == "fwd" else 3           # fwd read z + write a; bwd read dy, read z, write dz
         return self._bracket(self.norm, kind, float(passes) * c_real * rows * elem_bytes)
 
-    @staticmethod
-    def _sum(ent):
-        ms = sum(a.elapsed_time(b) for a, b in ent[0])
+    def calibrate(self, n=64):
+        """An event pair with nothing between its records still reads a few microseconds; with 23 short launches in one
+        family and 12 long ones in another that bias decides which family looks dominant.  Median of n empty brackets."""
+        pairs = []
+        for _ in range(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            e1.record()
+            pairs.append((e0, e1))
+        torch.cuda.synchronize()
+        self.overhead_ms = sorted(a.elapsed_time(b) for a, b in pairs)[n // 2]
+
+    def _sum(self, ent):
+        ms = sum(max(0.0, a.elapsed_time(b) - self.overhead_ms) for a, b in ent[0])
         return dict(launches=len(ent[0]), total_ms=ms, avg_ms=ms / max(1, len(ent[0])), work=ent[1])
 
     def dominant_conv(self, only_dtype=None):
@@ -363,6 +375,8 @@ def main():
     if mode == "hipgraph" and not a.no_probe and rank == 0 and world == 1:
         # inside a graph replay single kernels cannot be bracketed with events: time the same launches
         # (same tensors, same kernels) in an eager replica pass right after the timed region
+        gstep._eager_step()                 # unprobed: first eager pass after the replays (allocator, lazy state)
+        torch.cuda.synchronize()
         ops.CONV_PROBE, ops.NORM_PROBE = probe.conv_probe, probe.norm_probe
         probe.enabled = True
         for i in range(2):
@@ -371,6 +385,8 @@ def main():
         probe.enabled = False
         probe_mode = "eager replica pass (2 steps) right after the hipGraph-timed region"
     ops.CONV_PROBE = ops.NORM_PROBE = None
+    if not a.no_probe:
+        probe.calibrate()
 
     if rank == 0:
         vols = a.steps * a.batch * world
@@ -404,8 +420,8 @@ def main():
                                "algorithmic_bytes": probe.conv_bytes.get((pid, dcode), 0.0) / max(1, s["launches"]),
                                "traffic_over_algorithmic": (traffic / (probe.conv_bytes.get((pid, dcode), 0.0) / max(1, s["launches"]))) if traffic else None,
                                "kernel": name, "launches": s["launches"], "avg_launch_ms": s["avg_ms"],
-                               "share_of_conv_time": s["total_ms"] / max(1e-9, sum(Probe._sum(e)["total_ms"] for e in probe.conv.values())),
-                               "measured": probe_mode}
+                               "share_of_conv_time": s["total_ms"] / max(1e-9, sum(probe._sum(e)["total_ms"] for e in probe.conv.values())),
+                               "measured": probe_mode, "event_bracket_overhead_us": probe.overhead_ms * 1e3}
         ns = probe.norm_summary()
         if ns:
             hb = {}

@@ -332,8 +332,12 @@ __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, co
 #endif
     }
     pin_pipeline(3 * NG);
+#ifndef MARCH_DIAG_NO_WAIT
     dma_wait_all();
+#endif
+#ifndef MARCH_DIAG_NO_BARRIER
     __syncthreads();
+#endif
   };
   auto step = [&](int p, f32x16 (&s_m1)[4], f32x16 (&s_0)[4], f32x16 (&s_p1)[4]) __attribute__((always_inline)) {
     if (p < d0 - 1 || p > d1) return;                                 // wave-uniform: outside this segment's input planes
