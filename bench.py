@@ -123,8 +123,16 @@ class Probe:
         torch.cuda.synchronize()
         self.overhead_ms = sorted(a.elapsed_time(b) for a, b in pairs)[n // 2]
 
+    passes = 1      # identical step passes the brackets were collected over (2 for the eager replica after a graph run)
+
     def _sum(self, ent):
-        ms = sum(max(0.0, a.elapsed_time(b) - self.overhead_ms) for a, b in ent[0])
+        t = [max(0.0, a.elapsed_time(b) - self.overhead_ms) for a, b in ent[0]]
+        n = len(t) // self.passes
+        if self.passes > 1 and n * self.passes == len(t):
+            # the i-th launch of a family is the same launch in every pass: take its fastest reading (a bracket that
+            # happens to contain an allocator call or another one-off stall read 70 ms once) and scale back
+            t = [min(t[i + k * n] for k in range(self.passes)) for i in range(n)] * self.passes
+        ms = sum(t)
         return dict(launches=len(ent[0]), total_ms=ms, avg_ms=ms / max(1, len(ent[0])), work=ent[1])
 
     def dominant_conv(self, only_dtype=None):
@@ -379,7 +387,8 @@ def main():
         torch.cuda.synchronize()
         ops.CONV_PROBE, ops.NORM_PROBE = probe.conv_probe, probe.norm_probe
         probe.enabled = True
-        for i in range(2):
+        probe.passes = 2
+        for i in range(probe.passes):
             gstep._eager_step()
         torch.cuda.synchronize()
         probe.enabled = False
