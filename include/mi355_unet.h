@@ -61,8 +61,9 @@ int mi355_unpack_ncdhw(const void* src, float* dst, int32_t n, int32_t c, int64_
                        int32_t ld, int32_t coff, int32_t dtype, void* stream);
 /* Space-to-depth variants (PatchGAN path).  For a plain tensor a (N,D,H,W,C), even extents,
  *   S(a)[n, jd, jh, jw, blk*cblk + c] = a[n, 2jd+bd-1, 2jh+bh-1, 2jw+bw-1, c],  blk = 4bd+2bh+bw,
- * extents (D/2+1, H/2+1, W/2+1), 8*cblk channels per row (out-of-range cells stay zero: the caller
- * zero-fills S once).  The reference's Conv3d(k=4, s=2, p=1) (src/model.py:44,50) on a equals a
+ * extents (D/2+1, H/2+1, W/2+1), 8*cblk channels per row.  Blocks of the border cells that lie outside the volume
+ * hold zeros: the thread that writes a border voxel also writes them (the written channel range of every such
+ * block), so S needs no prior zero-fill once all its channels have been packed.  The reference's Conv3d(k=4, s=2, p=1) (src/model.py:44,50) on a equals a
  * dense k=2, s=1, p=0 convolution on S(a), so the PatchGAN runs on the stride-1 kernels.
  * pack:  writes channels [coff, coff+c) (zeros up to zero_to) of every block;  unpack: reads them. */
 int mi355_pack_ncdhw_s2d(const float* src, void* dst, int32_t n, int32_t c, int32_t d, int32_t h, int32_t w,

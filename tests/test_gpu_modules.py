@@ -90,7 +90,13 @@ def test_discriminator_golden(hip, golden_dir, tag, modality, n, s, cin):
     d = d.to(DEV).train()
     x, y = R.synthetic_batch(n, s, seed=1234, cin=cin)
     xd, yd = x.to(DEV), y.to(DEV).requires_grad_(True)
-    logits = d(xd, yd)
+    from unet_bssfp_amd import functional as Fn
+    Fn.S2D_POISON = True                  # space-to-depth tensors start as NaN: every slot must be written by the kernels
+    try:
+        logits = d(xd, yd)
+    finally:
+        Fn.S2D_POISON = False
+    assert bool(torch.isfinite(logits).all())
     loss = F.binary_cross_entropy_with_logits(logits, torch.ones_like(logits))
     loss.backward()
     np.testing.assert_allclose(logits.detach().cpu().numpy(), gold[f"{tag}/logits"], rtol=1e-3, atol=1e-4)

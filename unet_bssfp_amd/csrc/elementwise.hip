@@ -12,13 +12,32 @@ constexpr int kRowsPerStatBlock = 2048;
 // S(a)[n, jd, jh, jw, blk*C + c] = a[n, 2jd+bd-1, 2jh+bh-1, 2jw+bw-1, c], blk = bd*4 + bh*2 + bw, extents
 // (D/2+1, H/2+1, W/2+1): a k4 s2 p1 convolution of `a` is a dense k2 s1 p0 convolution of S(a).
 struct S2D { int d, h, w, cblk; };   // extents of the plain tensor (per sample); d == 0: off
-__device__ __forceinline__ long long s2d_offset(const S2D& q, long long row /* n*D*H*W + ... */, int ld) {
+// (cell row, block) of plain voxel `row`; `border`: bit set per axis (4 d, 2 h, 1 w) on which the voxel is the first or
+// last one -- the same cell's block with that parity bit flipped would read a[-1] / a[D]: it must hold zeros, and the
+// writer of the border voxel stores them (every slot of S(a) is then written by exactly one thread: the output
+// tensor needs no prior zero-fill).
+__device__ __forceinline__ void s2d_cell(const S2D& q, long long row /* n*D*H*W + ... */, long long& srow, int& blk, int& border) {
   const int w = (int)(row % q.w); long long t = row / q.w;
   const int h = (int)(t % q.h); t /= q.h;
   const int d = (int)(t % q.d); const long long n = t / q.d;
-  const long long srow = ((n * (q.d / 2 + 1) + ((d + 1) >> 1)) * (q.h / 2 + 1) + ((h + 1) >> 1)) * (q.w / 2 + 1) + ((w + 1) >> 1);
-  const int blk = ((d + 1) & 1) * 4 + ((h + 1) & 1) * 2 + ((w + 1) & 1);
+  srow = ((n * (q.d / 2 + 1) + ((d + 1) >> 1)) * (q.h / 2 + 1) + ((h + 1) >> 1)) * (q.w / 2 + 1) + ((w + 1) >> 1);
+  blk = ((d + 1) & 1) * 4 + ((h + 1) & 1) * 2 + ((w + 1) & 1);
+  border = ((d == 0 || d == q.d - 1) ? 4 : 0) | ((h == 0 || h == q.h - 1) ? 2 : 0) | ((w == 0 || w == q.w - 1) ? 1 : 0);
+}
+__device__ __forceinline__ long long s2d_offset(const S2D& q, long long row, int ld) {
+  long long srow; int blk, border;
+  s2d_cell(q, row, srow, blk, border);
   return srow * ld + (long long)blk * q.cblk;
+}
+// zeros into [e0, e0 + 16 B) of the border voxel's sibling blocks (all non-empty subsets of the border axes)
+template <typename T>
+__device__ __forceinline__ void s2d_zero_siblings(T* base, const S2D& q, long long srow, int blk, int border, int ld, int e0) {
+  if (!border) return;
+  Vec16<T> z;
+#pragma unroll
+  for (int j = 0; j < Vec16<T>::N; ++j) z.f[j] = 0.f;
+  for (int sub = 1; sub < 8; ++sub)
+    if ((sub & ~border) == 0) z.store(base + srow * ld + (long long)(blk ^ sub) * q.cblk + e0);
 }
 
 // ------------------------------------------------------------------ pack / unpack
@@ -34,7 +53,9 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src
   if (vox >= v) return;
   const float* s = src + (long long)n * c * v + vox;
   const float* s1 = src1 ? src1 + (long long)n * c1 * v + vox : nullptr;
-  T* drow = q.d ? dst + s2d_offset(q, (long long)n * v + vox, ld) : dst + ((long long)n * v + vox) * ld;
+  long long srow = 0; int blk = 0, border = 0;
+  if (q.d) s2d_cell(q, (long long)n * v + vox, srow, blk, border);
+  T* drow = q.d ? dst + srow * ld + (long long)blk * q.cblk : dst + ((long long)n * v + vox) * ld;
   for (int e0 = coff; e0 < zero_to; e0 += EPV) {
     Vec16<T> o;
 #pragma unroll
@@ -43,6 +64,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src
       o.f[j] = ch < c ? s[(long long)ch * v] : ((s1 && ch < c + c1) ? s1[(long long)(ch - c) * v] : 0.f);
     }
     o.store(drow + e0);
+    if (q.d) s2d_zero_siblings<T>(dst, q, srow, blk, border, ld, e0);
   }
 }
 
@@ -325,8 +347,12 @@ __global__ __launch_bounds__(256) void normact_fwd_kernel(const NormActArgs q) {
       if constexpr (DROP) t = (keep >> j) & 1u ? t * q.drop_scale : 0.f;
       v.f[j] = t > 0.f ? t : t * q.slope;
     }
-    if (q.s2d_a.d) v.store(reinterpret_cast<T*>(q.a) + s2d_offset(q.s2d_a, (long long)g * q.rows_per_group + row, q.lda) + ch0);
-    else v.store(ab + row * q.lda + ch0);
+    if (q.s2d_a.d) {
+      long long srow; int blk, border;
+      s2d_cell(q.s2d_a, (long long)g * q.rows_per_group + row, srow, blk, border);
+      v.store(reinterpret_cast<T*>(q.a) + srow * q.lda + (long long)blk * q.s2d_a.cblk + ch0);
+      s2d_zero_siblings<T>(reinterpret_cast<T*>(q.a), q.s2d_a, srow, blk, border, q.lda, ch0);
+    } else v.store(ab + row * q.lda + ch0);
   }
 }
 

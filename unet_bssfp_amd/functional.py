@@ -103,6 +103,17 @@ def _padded(vec: Optional[torch.Tensor], n: int, fill: float = 0.0) -> Optional[
 
 
 # ====================================================================================== backward stages
+S2D_POISON = False      # tests: fill new space-to-depth tensors with NaN to prove that the kernels write every slot
+
+
+def _new_s2d(shape, dtype, device):
+    """A space-to-depth output tensor.  Not zero-filled: the pack / norm+act kernels write every (cell, block) slot, the
+    out-of-volume blocks of the border cells included (elementwise.hip: s2d_zero_siblings)."""
+    if S2D_POISON:
+        return torch.full(shape, float("nan"), dtype=dtype, device=device)
+    return torch.empty(shape, dtype=dtype, device=device)
+
+
 class StageBoundary:
     """Collects, during a forward pass, the activations at which the backward pass can be cut into two stages (late
     layers first, early layers second) so that the late stage's gradient bucket is exchanged while the early stage's
@@ -170,7 +181,7 @@ class PackFn(Function):
             ctx.split = [s.shape[1] for s in srcs]
             srcs = (torch.cat([s.detach().to(torch.float32) for s in srcs], dim=1),)
         if s2d:
-            out = torch.zeros(ops.s2d_shape(n, d, h, w, cp), dtype=dtype, device=srcs[0].device)
+            out = _new_s2d(ops.s2d_shape(n, d, h, w, cp), dtype, srcs[0].device)
         else:
             out = ops.new_act(n, d, h, w, cp, dtype, srcs[0].device)
         offs, off = [], 0
@@ -566,7 +577,7 @@ class NormActFn(Function):
         seed = DropoutState.next_salt() if p > 0.0 else 0
         seed_t = DropoutState.base(z.device) if p > 0.0 else None
         if s2d_out:
-            out = torch.zeros(ops.s2d_shape(n, d, h, w, c), dtype=z.dtype, device=z.device)
+            out = _new_s2d(ops.s2d_shape(n, d, h, w, c), z.dtype, z.device)
             a = ops.normact_fwd(z, groups, mean, rstd, gp, bp, cfg.slope, p, seed, out=out, s2d=True, seed_t=seed_t)
         else:
             a = ops.normact_fwd(z, groups, mean, rstd, gp, bp, cfg.slope, p, seed, seed_t=seed_t)

@@ -100,7 +100,8 @@ def s2d_shape(n, d, h, w, cblk):
 
 
 def pack_ncdhw_s2d(src: torch.Tensor, dst: torch.Tensor, cblk: int, coff: int, zero_to: int):
-    """Like pack_ncdhw, but dst is S(a) (pre-zeroed): every plain voxel goes to its (cell, block)."""
+    """Like pack_ncdhw, but dst is S(a): every plain voxel goes to its (cell, block); the out-of-volume blocks of the
+    border cells get zeros in the written channel range (dst needs no prior zero-fill once all channels are packed)."""
     require_cuda(src, dst)
     assert src.dtype == torch.float32 and src.is_contiguous() and src.dim() == 5
     n, c, d, h, w = src.shape
@@ -110,7 +111,7 @@ def pack_ncdhw_s2d(src: torch.Tensor, dst: torch.Tensor, cblk: int, coff: int, z
 
 def pack2(src0: torch.Tensor, src1: torch.Tensor, dst: torch.Tensor, coff: int, zero_to: int, s2d_cblk: int = 0):
     """torch.cat([src0, src1], 1) packed in ONE pass (whole rows): channels coff.. <- src0 then src1, zeros up to
-    zero_to; s2d_cblk > 0: dst is the (pre-zeroed) space-to-depth tensor with that many channels per block."""
+    zero_to; s2d_cblk > 0: dst is the space-to-depth tensor with that many channels per block (fully written)."""
     require_cuda(src0, src1, dst)
     for t in (src0, src1):
         assert t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 5
@@ -421,7 +422,7 @@ def _norm_probe(kind, z, gamma):
 
 
 def normact_fwd(z, groups, mean, rstd, gamma, beta, slope, drop_p=0.0, seed=0, out=None, s2d=False, seed_t=None):
-    """s2d=True: `out` is the pre-zeroed space-to-depth tensor S(a) (s2d_shape) instead of a plain one."""
+    """s2d=True: `out` is the space-to-depth tensor S(a) (s2d_shape) instead of a plain one; every slot of it is written."""
     require_cuda(z, mean, rstd, gamma, beta, out)
     if out is None:
         out = torch.empty(z.shape, dtype=z.dtype, device=z.device)
