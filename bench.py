@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-probe", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend at world size > 1 (nccl = RCCL; gloo: rehearsal of the multi-rank path, ranks may share a GPU)")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of as hipGraph replays")
     ap.add_argument("--fresh-batch", action="store_true", help="a new host batch every step (H2D hidden on a side stream)")
     ap.add_argument("--lib", default=None, help="developer A/B: another build of the C ABI (tools/diaglib.py); reported")
@@ -277,12 +279,19 @@ def main():
         sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if a.backend != "nccl":
+        local = local % torch.cuda.device_count()        # rehearsal of the multi-rank path on fewer GPUs than ranks (gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
     nondefault = {k: v for k, v in os.environ.items() if k.startswith("MI355_") and k != "MI355_HOST_CORES"}
+    if a.backend != "nccl":
+        nondefault["backend"] = a.backend
     if a.lib:
         from tools import diaglib
         nondefault["lib"] = diaglib.use(a.lib)
@@ -347,7 +356,15 @@ def main():
     # settle: keep the chip under the same load until it has been busy for --settle-s (clock / thermal steady state)
     settle_steps = 0
     t_s = time.perf_counter()
-    while time.perf_counter() - t_s < a.settle_s:
+    while True:
+        more = time.perf_counter() - t_s < a.settle_s
+        if world > 1:
+            # every rank must run the SAME number of steps (each step holds collectives): go on while any rank wants to
+            flag = torch.tensor([1.0 if more else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            more = bool(flag.item() > 0.0)
+        if not more:
+            break
         for _ in range(5):
             step(a.warmup + settle_steps)
             settle_steps += 1
