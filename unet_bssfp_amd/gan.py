@@ -320,6 +320,12 @@ class bSSFPToDWITensorModel(nn.Module):
         return torch.stack([self.last_logs[k].reshape(()).float() for k in LOG_KEYS])
 
 
+# hipStreamCaptureModeThreadLocal: with a process group alive, c10d's watchdog thread polls the events of earlier
+# collectives (hipEventQuery); under the default global mode such a call from ANOTHER thread invalidates a capture in
+# progress.  Nothing unsafe is called from the capturing thread itself.
+CAPTURE_MODE = "thread_local"
+
+
 class GraphedTrainingStep:
     """The training step as hipGraph replays (HIP graphs instead of ~600 eager launches per step).
 
@@ -366,23 +372,23 @@ class GraphedTrainingStep:
         logs = self.logs
         if not self.segmented:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                 model._phase_gen(batch, logs)
                 model._phase_gen_update_discr(batch, logs)
                 model._phase_discr_update()
             self.graphs = [g]
         else:
             gs = [torch.cuda.CUDAGraph() for _ in range(5)]
-            with torch.cuda.graph(gs[0]):
+            with torch.cuda.graph(gs[0], capture_error_mode=CAPTURE_MODE):
                 model._phase_gen(batch, logs, staged=True)
-            with torch.cuda.graph(gs[1], pool=gs[0].pool()):
+            with torch.cuda.graph(gs[1], pool=gs[0].pool(), capture_error_mode=CAPTURE_MODE):
                 model._backward_early()
-            with torch.cuda.graph(gs[2], pool=gs[0].pool()):
+            with torch.cuda.graph(gs[2], pool=gs[0].pool(), capture_error_mode=CAPTURE_MODE):
                 model._update_gen()
                 model._phase_discr(batch, logs, staged=True)
-            with torch.cuda.graph(gs[3], pool=gs[0].pool()):
+            with torch.cuda.graph(gs[3], pool=gs[0].pool(), capture_error_mode=CAPTURE_MODE):
                 model._backward_early()
-            with torch.cuda.graph(gs[4], pool=gs[0].pool()):
+            with torch.cuda.graph(gs[4], pool=gs[0].pool(), capture_error_mode=CAPTURE_MODE):
                 model._phase_discr_update()
             self.graphs = gs
         model.last_logs = logs
