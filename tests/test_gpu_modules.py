@@ -189,6 +189,42 @@ def test_generator_odd_skip_extents_replicate_pad(hip):
         assert err <= 5e-3 * gr.norm() + 1e-7, (name, float(err), float(gr.norm()))
 
 
+def test_basic_unet_spatial_dims_2_matches_oracle(hip):
+    """BASELINE.json configs[0] (2-D U-Net 1 -> 6 channels on 64 x 64 slices): MONAI's 2-D parameter names / shapes and
+    default initialisation (same RNG consumption as the torch 2-D modules), forward and parameter gradients vs the oracle's
+    2-D network (oracle/unet_ref.py: RefBasicUNet(spatial_dims=2)), f32."""
+    from unet_bssfp_amd import BasicUNet
+    torch.manual_seed(31)
+    net = BasicUNet(spatial_dims=2, in_channels=1, out_channels=6, dropout=0.0)
+    torch.manual_seed(31)
+    ref = R.RefBasicUNet(spatial_dims=2, in_channels=1, out_channels=6, dropout=0.0).train()
+    sd, sr = net.state_dict(), ref.state_dict()
+    assert list(sd.keys()) == list(sr.keys())
+    for k in sd:
+        assert sd[k].shape == sr[k].shape, k
+        assert torch.equal(sd[k], sr[k]), k                           # identical default initialisation
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 1, 64, 64, generator=g)
+    y = torch.rand(2, 6, 64, 64, generator=g)
+    y_ref = ref(x)
+    (y_ref - y).abs().mean().backward()
+    net = net.to(DEV).train()
+    y_hip = net(x.to(DEV))
+    assert y_hip.shape == (2, 6, 64, 64)
+    (y_hip - y.to(DEV)).abs().mean().backward()
+    assert (y_hip.detach().cpu() - y_ref.detach()).abs().mean().item() <= 1e-4
+    torch.testing.assert_close(y_hip.detach().cpu(), y_ref.detach(), rtol=2e-3, atol=2e-4)
+    refp = dict(ref.named_parameters())
+    for name, p in net.named_parameters():
+        gr, gh = refp[name].grad, p.grad.cpu()
+        assert gh.shape == gr.shape, name
+        if name.endswith(".conv.bias"):                               # zero by construction in front of a normalisation
+            assert float(gh.abs().max()) <= 1e-5, name
+            continue
+        err = (gh - gr).norm()
+        assert err <= 5e-3 * gr.norm() + 1e-7, (name, float(err), float(gr.norm()))
+
+
 def test_reference_construction_site_drop_in(hip):
     """A reference-style Generator.forward (src/model.py:36-39) chaining the PUBLIC forwards of our
     DownSampleConv and BasicUNet gives the same result as our fused Generator (zero-copy hand-off)."""

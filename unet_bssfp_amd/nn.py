@@ -330,8 +330,10 @@ class BasicUNet(_Mi355Module):
                  act=("LeakyReLU", {"negative_slope": 0.1, "inplace": True}),
                  norm=("instance", {"affine": True}), bias: bool = True, dropout=0.0, upsample: str = "deconv"):
         super().__init__()
-        if spatial_dims != 3:
-            raise NotImplementedError("the MI355X path implements the reference's 3-D configuration")
+        if spatial_dims not in (2, 3):
+            raise NotImplementedError("spatial_dims must be 2 or 3")
+        self.spatial_dims = spatial_dims
+        rng_state = torch.get_rng_state() if spatial_dims == 2 else None
         if upsample != "deconv" or not bias:
             raise NotImplementedError("only upsample='deconv', bias=True (the reference's configuration)")
         act_name = act[0] if isinstance(act, (tuple, list)) else act
@@ -352,6 +354,51 @@ class BasicUNet(_Mi355Module):
         self.upcat_2 = UpCat(f[2], f[1], f[1], dropout)
         self.upcat_1 = UpCat(f[1], f[0], f[5], dropout, halves=False)
         self.final_conv = Conv3d(f[5], out_channels, kernel_size=1)
+        if spatial_dims == 2:
+            self._make_2d(rng_state)
+
+    # ---- spatial_dims = 2 (BASELINE.json configs[0], the reference's CPU-runnable plumbing case) ---------------------------
+    # The 2-D network runs on the 3-D kernels: parameters are registered with MONAI's 2-D names and shapes ((co, ci, 3, 3),
+    # (ci, co, 2, 2)) and embedded per call -- a 3x3 kernel becomes the kd = 1 plane of a 3x3x3 kernel (the other planes
+    # zero), a 2x2 transposed-conv kernel is repeated along kd -- and the (N, C, H, W) input is repeated over 16 d-slices,
+    # which four 2x poolings reduce to one.  Every slice then holds the 2-D network's values (a convolution never mixes
+    # slices, pooling and statistics of identical slices are the 2-D ones) and the mean over the slices is returned, so that
+    # the incoming gradient is spread over them and every parameter gradient is the 2-D one (backward is linear and the
+    # activations are identical across slices).  16x the 2-D FLOPs: a plumbing configuration, not a performance path.
+    # Element-wise dropout draws an independent mask per slice (same expectation, 1/16 of the variance).
+    _REPL = 16
+
+    def _make_2d(self, rng_state):
+        torch.set_rng_state(rng_state)                 # consume the RNG exactly like the 2-D torch modules would
+        for m in self.modules():
+            if isinstance(m, (Conv3d, ConvTranspose3d)):
+                k = m.weight.shape[-1]
+                m.weight = nn.Parameter(torch.empty(*m.weight.shape[:2], k, k))
+                nn.init.kaiming_uniform_(m.weight, a=math.sqrt(5))
+                if m.bias is not None:
+                    fan_in, _ = nn.init._calculate_fan_in_and_fan_out(m.weight)
+                    bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+                    nn.init.uniform_(m.bias, -bound, bound)
+
+    def _embedded_parameters(self):
+        deconv_w = {id(m.weight) for m in self.modules() if isinstance(m, ConvTranspose3d)}
+        out = {}
+        for name, p in self.named_parameters():
+            if p.dim() == 4 and id(p) in deconv_w:
+                out[name] = p.unsqueeze(2).expand(-1, -1, 2, -1, -1).contiguous()
+            elif p.dim() == 4:
+                w = p.unsqueeze(2)
+                out[name] = torch.nn.functional.pad(w, (0, 0, 0, 0, 1, 1)) if p.shape[-1] == 3 else w
+            else:
+                out[name] = p
+        return out
+
+    def _forward_2d(self, x):
+        if x.dim() != 4:
+            raise ValueError(f"spatial_dims=2 expects (N, C, H, W), got {tuple(x.shape)}")
+        x3 = x.unsqueeze(2).expand(-1, -1, self._REPL, -1, -1).contiguous()
+        y3 = torch.func.functional_call(self, self._embedded_parameters(), (x3,), {"_embedded": True})
+        return y3.mean(2)
 
     def forward_act(self, x):
         d, h, w = x.shape[1:4]
@@ -376,7 +423,9 @@ class BasicUNet(_Mi355Module):
         z, _ = self.final_conv.forward_act(u1)
         return z
 
-    def forward(self, x):
+    def forward(self, x, _embedded: bool = False):
+        if self.spatial_dims == 2 and not _embedded:
+            return self._forward_2d(x)
         z = self.forward_act(self._to_act(x, round_up(self.in_channels, 16)))
         return Fn.UnpackFn.apply(z, self.out_channels)
 
