@@ -79,8 +79,10 @@ def test_constructor_signatures_of_the_construction_sites():
                            "dropout", "upsample"]                                               # MONAI 1.3.0
     u = M.BasicUNet(spatial_dims=3, in_channels=24, out_channels=6, features=(32, 64, 128, 256, 512, 32), dropout=0.05)
     assert u.upcat_1.convs.conv_0.conv.weight.shape == (32, 96, 3, 3, 3)
+    u2 = M.BasicUNet(spatial_dims=2, in_channels=1, out_channels=6)             # BASELINE configs[0]: MONAI's 2-D shapes
+    assert u2.upcat_1.convs.conv_0.conv.weight.shape == (32, 64, 3, 3) and u2.upcat_1.upsample.deconv.weight.shape == (32, 32, 2, 2)
     with pytest.raises(NotImplementedError):
-        M.BasicUNet(spatial_dims=2, in_channels=1, out_channels=6)
+        M.BasicUNet(spatial_dims=1, in_channels=1, out_channels=6)
     with pytest.raises(NotImplementedError):
         M.BasicUNet(spatial_dims=3, in_channels=1, out_channels=6, upsample="nontrainable")
 
