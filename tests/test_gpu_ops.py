@@ -169,7 +169,14 @@ def test_conv_fwd_bwd(hip, case, dtype):
     assert bool((e0 <= 2e-3 * (n_pos * (zc * zc).sum((0, 2, 3, 4))).sqrt() + 1e-6).all()), e0.max()
     close_f32_sum(s[1, :cout], (zc * zc).sum((0, 2, 3, 4)), "sum (z-b)^2")
     # backward
-    z.backward(to_act(gz, dtype))
+    kinds = []
+    _ops().WGRAD_PROBE = lambda kind, d: kinds.append(kind)
+    try:
+        z.backward(to_act(gz, dtype))
+    finally:
+        _ops().WGRAD_PROBE = None
+    if (name.startswith("k3_ru") or name.startswith("k3_march")) and dtype == torch.bfloat16:
+        assert kinds == [2], kinds                                       # wgrad_march_kernel (3x3x3, W >= 32, D >= 8)
     off = 0
     for a, c in zip(acts, cins):
         close(from_act(a.grad, c), xcat.grad[:, off:off + c], dtype, "dx")

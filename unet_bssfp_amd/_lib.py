@@ -75,6 +75,7 @@ _SIGNATURES = {
     "mi355_conv_plan_id": (C.c_int, [C.POINTER(ConvDesc)]),
     "mi355_conv_num_tiles": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(_i32), C.POINTER(_i32)]),
     "mi355_conv_wgrad_workspace": (_i64, [C.POINTER(WgradDesc)]),
+    "mi355_conv_wgrad_plan_kind": (C.c_int, [C.POINTER(WgradDesc)]),
     "mi355_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc), _vp]),
     "mi355_channel_stats": (C.c_int, [_vp, _i32, _i32, _i64, _i32, _vp, _i32, _i32, _vp]),
     "mi355_channel_stats_blocks": (_i32, [_i64]),

@@ -842,6 +842,12 @@ extern "C" int64_t mi355_conv_wgrad_workspace(const mi355_wgrad_desc* d) {
   return (int64_t)p.nslabs * p.ks * p.ks * p.ks * p.cinp32 * p.coutp32 * 4;
 }
 
+extern "C" int mi355_conv_wgrad_plan_kind(const mi355_wgrad_desc* d) {
+  WPlan p;
+  if (wplan(d, &p)) return -1;
+  return p.march ? 2 : (p.fast ? 1 : 0);
+}
+
 extern "C" int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream) {
   WPlan p;
   int rc = wplan(d, &p);

@@ -255,6 +255,9 @@ def conv_fwd(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os=1, ooff=(0,
         after()
 
 
+WGRAD_PROBE = None      # tests: called as probe(plan kind, desc) before a weight-gradient launch (2 = marching kernel)
+
+
 def conv_wgrad(x0, x1, g, grid, gs, goff, ks, stride, pad, dw, cout, cin, s_co, s_ci, s_k, tbase, tstep,
                accumulate=False, s2d_cp=0, g_cls_cout=0):
     """dw (torch layout, f32) (+)= sum_p x[p*stride+tap-pad] * g[p*gs+goff]."""
@@ -288,6 +291,8 @@ def conv_wgrad(x0, x1, g, grid, gs, goff, ks, stride, pad, dw, cout, cin, s_co, 
     need = lib.mi355_conv_wgrad_workspace(C.byref(d))
     if need < 0:
         _lib.check(-1, "conv_wgrad_workspace")
+    if WGRAD_PROBE is not None:
+        WGRAD_PROBE(lib.mi355_conv_wgrad_plan_kind(C.byref(d)), d)
     ws = torch.empty((need // 4,), dtype=torch.float32, device=x0.device)
     d.workspace, d.workspace_bytes = ws.data_ptr(), need
     _lib.check(lib.mi355_conv_wgrad(C.byref(d), _stream()), "conv_wgrad")
