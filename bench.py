@@ -73,6 +73,13 @@ def parse():
                     help="torch.distributed backend at world size > 1 (nccl = RCCL; gloo: rehearsal of the multi-rank path, ranks may share a GPU)")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of as hipGraph replays")
     ap.add_argument("--fresh-batch", action="store_true", help="a new host batch every step (H2D hidden on a side stream)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="one rank, real process group: run the FIVE-segment graph step and issue its four all-reduces "
+                         "(rehearsal of process group + watchdog + thread-local capture on a single GPU)")
+    ap.add_argument("--bn-broadcast-every", type=int, default=1,
+                    help="world size > 1: broadcast rank 0's BatchNorm running statistics before every k-th step "
+                         "(DDP's broadcast_buffers=True, src/train.py:30; 0 = never)")
+    ap.add_argument("--master-port", type=int, default=0, help="self-launch (--gpus N without torch.distributed.run): rendezvous port (0 = pick a free one)")
     ap.add_argument("--lib", default=None, help="developer A/B: another build of the C ABI (tools/diaglib.py); reported")
     return ap.parse_args()
 
@@ -125,17 +132,30 @@ class Probe:
         torch.cuda.synchronize()
         self.overhead_ms = sorted(a.elapsed_time(b) for a, b in pairs)[n // 2]
 
-    passes = 1      # identical step passes the brackets were collected over (2 for the eager replica after a graph run)
+    passes = 1      # identical step passes the brackets were collected over (3 for the eager replica after a graph run)
 
     def _sum(self, ent):
+        """Per family: the MEAN over the probe passes of every launch's reading (what a profile's average duration shows:
+        ``avg_ms`` / ``total_ms``), the per-launch MINIMUM separately (``best_ms``), and the number of readings set aside
+        as one-off stalls (an allocator call or a page fault inside a bracket read 70 ms once): the i-th launch of a family
+        is the same launch in every pass, so a reading above 3x that launch's own minimum is flagged and not averaged."""
         t = [max(0.0, a.elapsed_time(b) - self.overhead_ms) for a, b in ent[0]]
-        n = len(t) // self.passes
+        n = len(t) // max(1, self.passes)
+        flagged = 0
         if self.passes > 1 and n * self.passes == len(t):
-            # the i-th launch of a family is the same launch in every pass: take its fastest reading (a bracket that
-            # happens to contain an allocator call or another one-off stall read 70 ms once) and scale back
-            t = [min(t[i + k * n] for k in range(self.passes)) for i in range(n)] * self.passes
-        ms = sum(t)
-        return dict(launches=len(ent[0]), total_ms=ms, avg_ms=ms / max(1, len(ent[0])), work=ent[1])
+            mean_t, best_t = [], []
+            for i in range(n):
+                r = [t[i + k * n] for k in range(self.passes)]
+                lo = min(r)
+                keep = [v for v in r if v <= 3.0 * lo + 1e-3]
+                flagged += len(r) - len(keep)
+                mean_t.append(sum(keep) / len(keep))
+                best_t.append(lo)
+            ms, best = sum(mean_t) * self.passes, sum(best_t) * self.passes
+        else:
+            ms = best = sum(t)
+        nl = max(1, len(ent[0]))
+        return dict(launches=len(ent[0]), total_ms=ms, avg_ms=ms / nl, best_ms=best / nl, work=ent[1], flagged=flagged)
 
     def dominant_conv(self, only_dtype=None):
         """(plan id, operand dtype code), summary of the convolution kernel family with the largest summed duration;
@@ -270,21 +290,48 @@ class FreshBatches:
         # the CPU thread for milliseconds, which must pass while the GPU is busy with the step, not in front of it
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(a) -> int:
+    """``python bench.py --gpus N`` without an external launcher: N rank processes via ``python -m torch.distributed.run``
+    started as a CHILD of this process, which has not initialised the GPU and does not (a process that has must never be
+    replaced by exec, and is not here); rank 0's JSON line passes through on stdout."""
+    import subprocess
+    port = a.master_port or free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: required for RCCL between processes on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // max(1, a.gpus))))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world == 1:
-        sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        # self-launch: this parent has not touched the GPU (no torch.cuda call so far) and never does -- it starts the
+        # ranks as fresh child processes through torch.distributed.run and relays rank 0's JSON line and the exit code
+        sys.exit(self_launch(a))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
     if a.backend != "nccl":
         local = local % torch.cuda.device_count()        # rehearsal of the multi-rank path on fewer GPUs than ranks (gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or a.force_collectives:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(a.master_port or free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -292,6 +339,8 @@ def main():
     nondefault = {k: v for k, v in os.environ.items() if k.startswith("MI355_") and k != "MI355_HOST_CORES"}
     if a.backend != "nccl":
         nondefault["backend"] = a.backend
+    if a.force_collectives:
+        nondefault["force_collectives"] = True
     if a.lib:
         from tools import diaglib
         nondefault["lib"] = diaglib.use(a.lib)
@@ -309,22 +358,12 @@ def main():
     batch = synthetic_batch(a.batch, a.size, seed=1234 + rank, device=dev)   # resident in HBM
     torch.manual_seed(1000 + rank)                         # dropout seeds differ per rank
     use_graph = not a.no_graph and a.workload == "gan_step"
-    gen_opt = None
 
     def eager_step(i):
-        nonlocal gen_opt
         if a.workload == "gan_step":
             model.training_step(batch, i)
         else:                                              # BASELINE.json configs[1]: generator only
-            if gen_opt is None:
-                gen_opt = model.optimizers()[0]
-            x, y = model.unpack_batch(batch)
-            loss = M.l1_loss(model.gen(x), y)
-            loss.backward()
-            if model.grad_sync_gen is not None:
-                model.grad_sync_gen.finish()
-            gen_opt.step()
-            gen_opt.zero_grad()
+            model.generator_only_step(batch, i)
 
     probe = Probe()
     mode = "eager"
@@ -334,7 +373,9 @@ def main():
         if world > 1:
             ddp.broadcast_module_state(model.gen, 0)
             ddp.broadcast_module_state(model.discr, 0)
-        gstep = GraphedTrainingStep(model, batch, warmup=2)    # 2 eager steps (allocations, caches, optimiser state) + capture
+        # 2 eager steps (allocations, caches, optimiser state) + capture
+        gstep = GraphedTrainingStep(model, batch, warmup=2, force_collectives=a.force_collectives,
+                                    broadcast_buffers_every=a.bn_broadcast_every)
         if a.fresh_batch:
             fresh = FreshBatches(gstep)
 
@@ -348,7 +389,11 @@ def main():
     else:
         if world > 1:
             ddp.attach(model)
-        step = eager_step
+
+        def step(i):
+            if world > 1:
+                ddp.broadcast_buffers(model, every=a.bn_broadcast_every, step=i)
+            eager_step(i)
 
     for i in range(a.warmup):
         step(i)
@@ -404,12 +449,12 @@ def main():
         torch.cuda.synchronize()
         ops.CONV_PROBE, ops.NORM_PROBE = probe.conv_probe, probe.norm_probe
         probe.enabled = True
-        probe.passes = 2
+        probe.passes = 3
         for i in range(probe.passes):
             gstep._eager_step()
         torch.cuda.synchronize()
         probe.enabled = False
-        probe_mode = "eager replica pass (2 steps) right after the hipGraph-timed region"
+        probe_mode = "eager replica passes (3 steps) right after the hipGraph-timed region; mean over the passes per launch"
     ops.CONV_PROBE = ops.NORM_PROBE = None
     if not a.no_probe:
         probe.calibrate()
@@ -428,6 +473,7 @@ def main():
                        "volume": f"{a.batch}x24x{a.size}^3 -> 6ch per GPU", "global_batch": a.batch * world,
                        "dropout": a.dropout, "perceptual_term": "absent (needs remote weights)",
                        "parallelism": f"dp{world}",
+                       "bn_buffer_broadcast_every": (a.bn_broadcast_every if world > 1 else None),
                        "input_feed": "new host batch every step, H2D on a side stream" if fresh is not None else "one batch resident in HBM"},
             "step_tflops": flop_per_vol * vols / dt / 1e12,
             "launch_mode": mode,
@@ -445,8 +491,16 @@ def main():
                                "frac": ach / PEAK_TFLOPS[a.dtype], "traffic": traffic, "traffic_source": tinfo,
                                "algorithmic_bytes": probe.conv_bytes.get((pid, dcode), 0.0) / max(1, s["launches"]),
                                "traffic_over_algorithmic": (traffic / (probe.conv_bytes.get((pid, dcode), 0.0) / max(1, s["launches"]))) if traffic else None,
-                               "kernel": name, "launches": s["launches"], "avg_launch_ms": s["avg_ms"],
+                               "kernel": name, "launches": s["launches"], "avg_launch_ms": s["avg_ms"], "best_launch_ms": s["best_ms"],
+                               "frac_best": s["work"] / (s["best_ms"] * s["launches"] * 1e-3) / 1e12 / PEAK_TFLOPS[a.dtype] if s["best_ms"] > 0 else None,
+                               "flagged_brackets": s["flagged"],
                                "share_of_conv_time": s["total_ms"] / max(1e-9, sum(probe._sum(e)["total_ms"] for e in probe.conv.values())),
+                               "conv_families": sorted(({"plan": PLAN_NAMES.get(k[0], str(k[0])), "operands": {0: "f32", 1: "bf16", 3: "e4m3"}.get(k[1], str(k[1])),
+                                                          "launches_per_step": v["launches"] // max(1, probe.passes),
+                                                          "ms_per_step": v["total_ms"] / max(1, probe.passes),
+                                                          "tflops": v["work"] / max(1e-9, v["total_ms"] * 1e-3) / 1e12, "flagged": v["flagged"]}
+                                                         for k, v in ((k, probe._sum(e)) for k, e in probe.conv.items())),
+                                                        key=lambda r: -r["ms_per_step"]),
                                "measured": probe_mode, "event_bracket_overhead_us": probe.overhead_ms * 1e3}
         ns = probe.norm_summary()
         if ns:
@@ -454,13 +508,13 @@ def main():
             for kind, s in ns.items():
                 gbs = s["work"] / (s["total_ms"] * 1e-3) / 1e9
                 hb[kind] = {"kernel": "normact_fwd_kernel" if kind == "fwd" else "normact_bwd (reduce + apply)",
-                            "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "launches": s["launches"], "total_ms": s["total_ms"] / 2,
+                            "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "launches": s["launches"], "total_ms": s["total_ms"] / max(1, probe.passes),
                             "algorithmic_bytes": "2*C*V*b (read z, write a)" if kind == "fwd" else "3*C*V*b (read dy, read z, write dz; the two-kernel form executes 5 passes)"}
             out["roofline_hbm"] = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernels": hb, "measured": probe_mode}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.size, a.workload, a.cpu_steps)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

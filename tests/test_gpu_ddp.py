@@ -58,6 +58,13 @@ def _worker(rank, world, port, mode, q):
             model.training_step(batch, 0)
             ops.conv_wgrad, gradsink.GradBuckets.launch = real_wgrad, real_launch
             extra = log
+        elif mode == "gen_only":
+            # BASELINE.json configs[1] on an attached model: a backward loop other than training_step must still average
+            # the gradients over the ranks (the ranks draw different batches: without the exchange they drift apart)
+            ddp.attach(model)
+            for i in range(3):
+                model.generator_only_step(batch, i)
+            extra = list(model.sinks_gen.launch_order)
         else:
             ddp.attach(model)
             for i in range(4):
@@ -121,3 +128,24 @@ def test_graph_and_hook_paths_agree_two_ranks(hip):
     assert all(r[1] == "ok" for r in a + b), [r[1] for r in a + b]
     da, db = torch.tensor(a[0][2]), torch.tensor(b[0][2])
     torch.testing.assert_close(da, db, rtol=1e-6, atol=1e-6)
+
+
+def test_generator_only_loop_on_an_attached_model_two_ranks(hip):
+    res = _run("gen_only")
+    assert all(r[1] == "ok" for r in res), [r[1] for r in res]
+    assert all(sorted(r[3]) == [0, 1] for r in res), [r[3] for r in res]      # both generator buckets were exchanged
+
+
+def test_zero_grad_on_sink_parameters_fails_loudly(hip):
+    """optimizer.zero_grad() (set_to_none=True by default) drops the permanent .grad views of the gradient sinks: the next
+    backward must raise a clear error instead of handing the kernels a null pointer."""
+    import unet_bssfp_amd as M
+    from unet_bssfp_amd.gan import bSSFPToDWITensorModel, synthetic_batch
+    torch.manual_seed(0)
+    model = bSSFPToDWITensorModel("bssfp", gen=M.Generator("bssfp", dropout=0.0).to("cuda:0"),
+                                  discr=M.Discriminator("bssfp").to("cuda:0")).train()
+    batch = synthetic_batch(2, 32, seed=1, device="cuda:0")
+    model.generator_only_step(batch, 0)
+    model.optimizers()[0].zero_grad()
+    with pytest.raises(RuntimeError, match="gradient bucket"):
+        model.generator_only_step(batch, 1)

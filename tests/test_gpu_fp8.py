@@ -141,3 +141,59 @@ def test_fp8_generator_and_training_track_bf16(hip):
                 fh.write(f"step {i}: " + " ".join(f"{k}={curves['bf16'][i][k]:.5f}/{curves['fp8'][i][k]:.5f}" for k in curves['bf16'][i]) + "\n")
     except OSError:
         pass
+
+
+def test_fp8_gan_step_at_config5_size_160(hip):
+    """BASELINE.json configs[4] itself: one full GAN training step on a 1 x 24 x 160^3 volume with
+    ``set_compute_dtype(model, "fp8")`` (src/train.py:33 is the reference's precision knob).  Size-independent properties:
+    finite losses and parameters, every used parameter moved by the two AdamW updates, a bit-identical rerun from the same
+    state; step-0 losses within 5e-3 (discriminator loss 2e-2) of a bf16-mode run of the same step -- the bounds
+    test_bf16_gan_step_at_config3_size_vs_f32_mode uses between bf16 and f32; and the e4m3 plan really was taken: the
+    CONV_PROBE records operand type 3 (e4m3) on the full-resolution 3x3x3 layers with 32 input channels (forward of
+    conv_0.conv_1 and upcat_1.conv_1 in both generator passes; the data gradients whose incoming gradient has 32 channels)."""
+    import copy
+    import unet_bssfp_amd as M
+    from unet_bssfp_amd import ops
+    from unet_bssfp_amd.ddp import used_parameters
+    from unet_bssfp_amd.gan import bSSFPToDWITensorModel, synthetic_batch
+    torch.manual_seed(0)
+    gen, discr = M.Generator("bssfp", dropout=0.0), M.Discriminator("bssfp")
+    state = copy.deepcopy((gen.state_dict(), discr.state_dict()))
+    batch = synthetic_batch(1, 160, seed=77, device=DEV)
+    logs, params, plans = {}, {}, []
+    for mode in ("bf16", "fp8", "fp8_again"):
+        g, d = M.Generator("bssfp", dropout=0.0), M.Discriminator("bssfp")
+        g.load_state_dict(state[0])
+        d.load_state_dict(state[1])
+        model = bSSFPToDWITensorModel("bssfp", gen=g.to(DEV), discr=d.to(DEV)).train()
+        M.set_compute_dtype(model, "bf16" if mode == "bf16" else "fp8")
+        before = [p.detach().clone() for p in used_parameters(model.gen, "bssfp") + used_parameters(model.discr, "bssfp")]
+        if mode == "fp8":
+            ops.CONV_PROBE = lambda pid, dd, real: plans.append((pid, int(dd.dtype), int(dd.c0), int(dd.cstore), int(dd.di))) and None
+        try:
+            model.training_step(batch, 0)
+        finally:
+            ops.CONV_PROBE = None
+        torch.cuda.synchronize()
+        logs[mode] = {k: float(v) for k, v in model.last_logs.items()}
+        params[mode] = [p.detach().clone() for p in model.parameters()]
+        if mode == "fp8":
+            after = used_parameters(model.gen, "bssfp") + used_parameters(model.discr, "bssfp")
+            assert all(not torch.equal(a, b) for a, b in zip(before, after)), "a used parameter did not move"
+        del model, g, d
+        torch.cuda.empty_cache()
+    e4m3 = [p for p in plans if p[1] == 3]
+    # every e4m3 launch is a full-resolution layer with 32 stored input channels on the marching plan ...
+    assert e4m3 and all(p[2] == 32 and p[4] == 160 and p[0] == 32041 for p in e4m3), e4m3      # 32041 = conv_march_kernel
+    # ... two generator forward passes x {conv_0.conv_0 (24 -> 32, stored as 32), conv_0.conv_1, upcat_1.conv_1} and the
+    # data gradients of conv_0.conv_1, upcat_1.conv_0 (32 -> 96), upcat_1.conv_1 (conv_0.conv_0's goes to a constant input)
+    assert len(e4m3) >= 8, e4m3
+    full_res_k3 = [p for p in plans if p[0] // 10000 == 3 and p[4] == 160 and p[2] == 32]
+    assert len(e4m3) == len(full_res_k3), (len(e4m3), len(full_res_k3))
+    for k, ref in logs["bf16"].items():
+        got = logs["fp8"][k]
+        assert np.isfinite(got)
+        assert abs(got - ref) <= (5e-3 if "discr" not in k else 2e-2) * abs(ref), (k, got, ref)
+    assert logs["fp8"] == logs["fp8_again"]
+    assert all(torch.equal(a, b) for a, b in zip(params["fp8"], params["fp8_again"]))
+    assert all(torch.isfinite(p).all() for p in params["fp8"])

@@ -458,7 +458,8 @@ def test_thesis_volume_96x128x128_forward_parity(hip):
 def test_config5_size_160_forward_parity_and_step(hip):
     """BASELINE.json configs[4] size (1x24x160^3: bottleneck 10^3, ragged 40/20/10-wide levels): f32 forward
     parity with the CPU oracle (per-voxel L1 <= 1e-4), then one full bf16 GAN step (finite losses, deterministic
-    forward).  The fp8 arithmetic that configuration names is not built (known gaps)."""
+    forward).  The e4m3 arithmetic that configuration names is exercised at this size by
+    tests/test_gpu_fp8.py::test_fp8_gan_step_at_config5_size_160."""
     import unet_bssfp_amd as M
     from unet_bssfp_amd import gan
     torch.manual_seed(0)

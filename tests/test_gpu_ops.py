@@ -120,6 +120,44 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("case", ["march", "ru", "halo"])
+def test_conv_fused_statistics_with_a_bias_far_from_zero(hip, case):
+    """A pre-norm conv bias that has random-walked far from zero (a loaded checkpoint; default init keeps |b| <= 0.04):
+    bias = 10 sigma(z - b).  The fused statistics must still be those of (z - b) to f32 summation accuracy -- a kernel that
+    accumulates sum z, sum z^2 and subtracts the bias terms afterwards loses ~2 decimal digits of the variance here
+    (cancellation of cnt * b^2 against sum z^2); every conv kernel accumulates (z - b) itself."""
+    from unet_bssfp_amd import functional as Fn
+    cins, sp, want = {"march": ((32,), (16, 64, 128), 32041), "ru": ((32, 64), (16, 64, 128), None),
+                      "halo": ((64,), (8, 16, 16), None)}[case]
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    layer = _conv_layer(cins, 32, 3, 1, 1, 3)
+    xs = [q(torch.rand(1, c, *sp, generator=g) - 0.5, dtype) for c in cins]
+    with torch.no_grad():
+        layer.weight.copy_(q(layer.weight, dtype))
+        zc = F.conv3d(torch.cat(xs, 1), layer.weight, None, 1, 1)
+        sigma = zc.std((0, 2, 3, 4))
+        layer.bias.copy_(10.0 * sigma * torch.where(torch.arange(32) % 2 == 0, 1.0, -1.0))
+    layer = layer.to(DEV)
+    acts = [to_act(x, dtype) for x in xs]
+    plans = []
+    _ops().CONV_PROBE = lambda pid, d, real: plans.append(pid)
+    try:
+        z, part = Fn.ConvFn.apply(acts[0], acts[1] if len(acts) > 1 else None, layer.weight, layer.bias, layer.spec, True)
+    finally:
+        _ops().CONV_PROBE = None
+    if want is not None:
+        assert plans == [want], plans
+    s = part.sum(0).double().cpu()
+    npos = zc.numel() / 32
+    ref1, ref2 = zc.double().sum((0, 2, 3, 4)), (zc.double() ** 2).sum((0, 2, 3, 4))
+    var_got = s[1, :32] / npos - (s[0, :32] / npos) ** 2
+    var_ref = ref2 / npos - (ref1 / npos) ** 2
+    assert float(((var_got - var_ref).abs() / var_ref).max()) <= 1e-4, ((var_got - var_ref).abs() / var_ref).max()
+    assert float(((s[1, :32] - ref2).abs() / ref2).max()) <= 1e-4
+    close(from_act(z, 32), zc + layer.bias.detach().cpu().view(1, -1, 1, 1, 1), dtype, "z")
+
+
 def _conv_layer(cins, cout, ks, stride, pad, seed):
     from unet_bssfp_amd.nn import Conv3d
     torch.manual_seed(seed)

@@ -154,7 +154,12 @@ __device__ __forceinline__ dma_rsrc_t dma_rsrc(const void* base, long long bytes
   return r;
 }
 // 64 lanes x 16 bytes -> LDS bytes [lds_addr + 16 * lane, + 16); source = base + soff + voff (per lane); a source offset
-// outside [0, bytes) yields zeros
+// outside [0, bytes) yields zeros.
+// M0: the statement overwrites m0 and cannot declare it (hipcc: "clobber list contains reserved registers: m0 ... may lead
+// to undefined behaviour").  It is safe only because the kernels that use it contain NO construct for which the compiler
+// itself sets or reads m0: no dynamically indexed register array (movrel-style v_movrel / s_set_gpr_idx), no
+// __builtin_amdgcn_raw_ptr_buffer_load_lds, no ds_*_addtid / LDS-direct / GWS / s_sendmsg use, no readlane with a
+// variable index lowered through m0.  Keep it that way in conv_march.h, conv_marchg.h and wgrad_march (wgrad.hip).
 __device__ __forceinline__ void dma_lds_b128(const dma_rsrc_t rs, const void* lds_dst, const int voff, const int soff) {
   const unsigned m = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)lds_dst;
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"

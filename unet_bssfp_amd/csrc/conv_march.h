@@ -168,26 +168,33 @@ __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, co
     const float ax = m.amax_x[0], aw = m.amax_w[0];
     deq = (ax > 0.f ? ax * (1.f / 224.f) : 1.f) * (aw > 0.f ? aw * (1.f / 224.f) : 1.f);
   }
-  // the bias (in accumulator units) is the accumulators' initial value (one LDS read of 16 floats where an output plane
-  // starts); the statistics are taken of z = acc * deq and turned into those of (z - bias) once, at the end
+  // The accumulators start at zero and hold z - bias (fp8: in units of deq); the fused statistics are taken of exactly
+  // that (no after-the-fact bias correction, which cancels when |bias| >> sigma(z - bias): a loaded checkpoint), and the
+  // bias is added where a finished row is converted for the store (16 values read from LDS, nothing resident).
   float s1[16], s2[16];
-  float* const blds = reinterpret_cast<float*>(patch) + 512;          // [32] bias / deq of this workgroup's channels
-  if (tid < 32) blds[tid] = ((a.bias && co_base + tid < a.nbias) ? a.bias[co_base + tid] : 0.f) / deq;
+  float* const blds = reinterpret_cast<float*>(patch) + 512;          // [32] bias of this workgroup's channels
+  if (tid < 32) blds[tid] = (a.bias && co_base + tid < a.nbias) ? a.bias[co_base + tid] : 0.f;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-  int nstat = 0;                                                      // voxels this lane has added to its sums
   const bool vox_ok = w0 + r < a.wo;
   const bool st0 = vox_ok && cch + 8 <= a.cstore, st1 = vox_ok && cch + 16 <= a.cstore;
 
   auto pack_row = [&](const f32x16& s, uint32_t (&w)[8], const bool stats) __attribute__((always_inline)) {
+    const float4* bp = reinterpret_cast<const float4*>(blds + 16 * h);
 #pragma unroll
-    for (int i = 0; i < 16; i += 2) {
-      const float v0 = s[i], v1 = s[i + 1];                           // accumulator units (fp8: z / deq); sums are rescaled once, at the end
+    for (int i4 = 0; i4 < 4; ++i4) {
+      const float4 bq = bp[i4];
+      const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+      for (int j = 0; j < 4; j += 2) {
+        const int i = 4 * i4 + j;
+        const float v0 = s[i], v1 = s[i + 1];                         // accumulator units (fp8: (z - bias) / deq); sums are rescaled once, at the end
 #ifndef MARCH_DIAG_NO_STATS
-      if (stats) { s1[i] += v0; s2[i] += v0 * v0; s1[i + 1] += v1; s2[i + 1] += v1 * v1; }
+        if (stats) { s1[i] += v0; s2[i] += v0 * v0; s1[i + 1] += v1; s2[i + 1] += v1 * v1; }
 #endif
-      w[i >> 1] = F8 ? ((uint32_t)f32_to_bf16_bits(v0 * deq) | ((uint32_t)f32_to_bf16_bits(v1 * deq) << 16))
-                     : ((uint32_t)f32_to_bf16_bits(v0) | ((uint32_t)f32_to_bf16_bits(v1) << 16));
+        const float z0 = F8 ? fmaf(v0, deq, bb[j]) : v0 + bb[j], z1 = F8 ? fmaf(v1, deq, bb[j + 1]) : v1 + bb[j + 1];
+        w[i >> 1] = (uint32_t)f32_to_bf16_bits(z0) | ((uint32_t)f32_to_bf16_bits(z1) << 16);
+      }
     }
   };
   // ---- epilogue of one finished output plane q (generic form): bf16, two 16-byte stores per lane and row
@@ -196,7 +203,6 @@ __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, co
     for (int row = 0; row < 4; ++row) {
       const int gh = h0 + 4 * wave + row;
       if (gh >= a.ho) break;                                          // wave-uniform
-      nstat += vox_ok ? 1 : 0;
       T* dst = reinterpret_cast<T*>(a.y) + ((((long long)tn * a.dy + q) * a.hy + gh) * a.wy + w0 + r) * a.ldy + cch;
       uint32_t w[8];
       pack_row(s[row], w, vox_ok);
@@ -204,13 +210,9 @@ __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, co
       if (st1) *reinterpret_cast<uint4*>(dst + 8) = make_uint4(w[4], w[5], w[6], w[7]);
     }
   };
-  auto init_row = [&](f32x16& s) __attribute__((always_inline)) {    // first contribution to an output row: C = bias
-    const float4* bp = reinterpret_cast<const float4*>(blds + 16 * h);
+  auto init_row = [&](f32x16& s) __attribute__((always_inline)) {    // first contribution to an output row: C = 0
 #pragma unroll
-    for (int i4 = 0; i4 < 4; ++i4) {
-      const float4 q = bp[i4];
-      s[4 * i4] = q.x; s[4 * i4 + 1] = q.y; s[4 * i4 + 2] = q.z; s[4 * i4 + 3] = q.w;
-    }
+    for (int i = 0; i < 16; ++i) s[i] = 0.f;
   };
 
   // ---- fragment groups.  The NEXT group's reads are issued ahead of this group's MFMAs (one wave per SIMD: nothing else
@@ -310,7 +312,6 @@ __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, co
       if (gi == NG - 1) asm volatile("" :: "v"(s_m1[0][0]), "v"(s_m1[1][5]), "v"(s_m1[2][9]), "v"(s_m1[3][15]));
 #else
       if (gi == NG - 1) {                                             // output plane p - 1 is complete
-        nstat += 4;
         const int ybase = ((tn * a.dy + (p - 1)) * a.hy + h0) * a.wy * a.ldy * 2;
 #pragma unroll
         for (int row = 0; row < 4; ++row) {
@@ -414,13 +415,9 @@ __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, co
     // one row of partial statistics per workgroup: the 32 voxel lanes of each half by shuffles, then the 4 waves through
     // LDS, fixed order (deterministic)
     float* red = reinterpret_cast<float*>(patch);
-    const float cnt = (float)nstat;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const float b = blds[16 * h + i] * deq;                         // sums of z -> sums of (z - bias)
-      if constexpr (F8) { s1[i] *= deq; s2[i] *= deq * deq; }
-      s2[i] = s2[i] - 2.f * b * s1[i] + cnt * b * b;
-      s1[i] = s1[i] - cnt * b;
+      if constexpr (F8) { s1[i] *= deq; s2[i] *= deq * deq; }         // the sums are already those of (z - bias)
 #pragma unroll
       for (int o = 1; o < 32; o <<= 1) {
         s1[i] += __shfl_xor(s1[i], o, 64);

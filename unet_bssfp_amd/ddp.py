@@ -164,7 +164,7 @@ def attach(model, bucket_mb: float = 25.0, group=None, broadcast: bool = True):
         broadcast_module_state(model.gen, 0, group)
         broadcast_module_state(model.discr, 0, group)
     modality = getattr(model, "input_modality", None)
-    if getattr(model, "enable_grad_sinks", None) is not None and model.enable_grad_sinks(group):
+    if getattr(model, "enable_grad_sinks", None) is not None and model.enable_grad_sinks(group, distributed=True):
         # HIP networks: the gradient kernels write into flat per-stage buckets (gradsink.py); a bucket is all-reduced the
         # moment its last gradient kernel has been enqueued, under the rest of the backward pass
         return model

@@ -14,7 +14,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import ops
-from .gradsink import sink_of
+from .gradsink import sink_grad, sink_of
 from .ops import round_up
 
 CLASSES8 = [(a, b, c) for a in (0, 1) for b in (0, 1) for c in (0, 1)]
@@ -462,7 +462,7 @@ class ConvFn(Function):
             weight = ctx.weight_param
             wsink = sink_of(weight)
             acc = wsink is not None and not wsink.fresh(weight)
-            dwt = weight.grad if wsink is not None else torch.empty_like(weight, dtype=torch.float32)
+            dwt = sink_grad(weight) if wsink is not None else torch.empty_like(weight, dtype=torch.float32)
             if ctx.s2d_cp:
                 ops.conv_wgrad(x0, None, dz, (do_, ho, wo), 1, (0, 0, 0), 2, 1, (0, 0, 0), dwt, spec.cout, spec.cin,
                                spec.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (2, 2, 2), s2d_cp=ctx.s2d_cp, accumulate=acc)
@@ -490,7 +490,7 @@ class ConvFn(Function):
                 else:
                     db = _cached_zeros(spec.cout, dev)
             elif bsink is not None:
-                ops.colsum_into(dz, ctx.bias_param.grad, accumulate=not bsink.fresh(ctx.bias_param))
+                ops.colsum_into(dz, sink_grad(ctx.bias_param), accumulate=not bsink.fresh(ctx.bias_param))
                 bsink.written(ctx.bias_param)
             else:
                 db = ops.colsum(dz)[: spec.cout].contiguous()
@@ -600,7 +600,7 @@ class NormActFn(Function):
         if sink is not None and sink_of(beta_p) is sink:
             # both affine gradients straight into the parameters' .grad storage (gradsink.py)
             dz, _, _ = ops.normact_bwd(z, da, groups, mean, rstd, gp, bp, slope, p, seed, batch_stats, True,
-                                       s2d=ctx.s2d_out, seed_t=ctx.seed_t, affine_into=(gamma_p.grad, beta_p.grad),
+                                       s2d=ctx.s2d_out, seed_t=ctx.seed_t, affine_into=(sink_grad(gamma_p), sink_grad(beta_p)),
                                        accumulate=not sink.fresh(gamma_p))
             sink.written(gamma_p)
             sink.written(beta_p)

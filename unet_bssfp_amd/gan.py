@@ -27,6 +27,11 @@ import torch.nn.functional as F
 
 DATA = "data"  # tio.DATA
 
+
+def dist_world(group=None) -> int:
+    import torch.distributed as dist
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
 # the reference's log names (src/model.py:177, 204-210, 266, 276): EarlyStopping monitors 'val_gen_loss_recon' (src/train.py:19)
 LOG_KEYS = ("train_gen_loss_adversarial", "train_gen_loss_recon_L1", "train_gen_loss_recon", "train_gen_loss",
             "train_discr_loss")
@@ -136,21 +141,30 @@ class bSSFPToDWITensorModel(nn.Module):
             p.requires_grad_(flag)
 
     # ------------------------------------------------------------------ gradient storage / exchange
-    def enable_grad_sinks(self, group=None) -> bool:
+    def enable_grad_sinks(self, group=None, distributed: bool = False, force_collectives: bool = False) -> bool:
         """HIP networks on the GPU: parameter gradients live in flat per-stage buckets that the gradient kernels write
         in place (gradsink.py).  Bucket 0 = the layers whose gradients are ready first (decoder + bottleneck of the
         U-Net; d3..final of the PatchGAN), bucket 1 = the rest; with world size > 1 a bucket is all-reduced as soon as
-        it is complete, under the remaining backward kernels."""
+        it is complete, under the remaining backward kernels.  ``distributed`` is set by ``ddp.attach`` and
+        ``GraphedTrainingStep`` only: a plain ``training_step`` never starts collectives on its own."""
         if self.sinks_gen is not None:
-            return True
+            want = distributed and (dist_world(group) > 1 or force_collectives)
+            if not want or self.sinks_gen.exchange:
+                return True
+            # created local-only by an earlier plain step: rebuild with the exchange switched on
+            self.sinks_gen.detach()
+            self.sinks_discr.detach()
+            self.sinks_gen = self.sinks_discr = None
         if not self.use_grad_sinks:
             return False
         from .nn import Discriminator, Generator, backward_stages
         if not (isinstance(self.gen, Generator) and isinstance(self.discr, Discriminator) and next(self.gen.parameters()).is_cuda):
             return False
         from .gradsink import GradBuckets
-        self.sinks_gen = GradBuckets(backward_stages(self.gen, self.input_modality), group, uses_per_phase=1)
-        self.sinks_discr = GradBuckets(backward_stages(self.discr, self.input_modality), group, uses_per_phase=2)
+        self.sinks_gen = GradBuckets(backward_stages(self.gen, self.input_modality), group, uses_per_phase=1,
+                                     distributed=distributed, force_collectives=force_collectives)
+        self.sinks_discr = GradBuckets(backward_stages(self.discr, self.input_modality), group, uses_per_phase=2,
+                                       distributed=distributed, force_collectives=force_collectives)
         return True
 
     def _finish_grads(self, which: str):
@@ -175,6 +189,15 @@ class bSSFPToDWITensorModel(nn.Module):
         assert all(g is None for g in grads[len(boundary):]), "staged backward needs gradient sinks"
         self._stage = (boundary, list(grads[: len(boundary)]), [p for p in sinks.params[1] if p.requires_grad])
 
+    @staticmethod
+    def _close_stage_boundary():
+        """An exception between StageBoundary.begin() and the staged backward must not leave the process-global collector
+        open (every later forward would keep appending -- and keeping alive -- activations)."""
+        import sys
+        fn = sys.modules.get(__package__ + ".functional")       # (never imported on the CPU-module path: nothing to close)
+        if fn is not None and fn.StageBoundary.active():
+            fn.StageBoundary.end()
+
     def _backward_early(self):
         boundary, grads, early = self._stage
         self._stage = None
@@ -194,9 +217,12 @@ class bSSFPToDWITensorModel(nn.Module):
                 self._stage_sinks = self.sinks_gen
                 StageBoundary.begin()
         self._toggle(self.discr, False)
-        loss, _ = self._gen_step(x, y, logs)
-        logs["train_gen_loss"] = loss.detach()
-        self._backward(loss, staged)
+        try:
+            loss, _ = self._gen_step(x, y, logs)
+            logs["train_gen_loss"] = loss.detach()
+            self._backward(loss, staged)
+        finally:
+            self._close_stage_boundary()
 
     def _update_gen(self):
         """gen_opt.step/zero_grad/untoggle                             (:269-271)"""
@@ -217,9 +243,12 @@ class bSSFPToDWITensorModel(nn.Module):
             from .functional import StageBoundary
             self._stage_sinks = self.sinks_discr
             StageBoundary.begin()
-        loss = self._discr_step(x, y)
-        logs["train_discr_loss"] = loss.detach()
-        self._backward(loss, staged)
+        try:
+            loss = self._discr_step(x, y)
+            logs["train_discr_loss"] = loss.detach()
+            self._backward(loss, staged)
+        finally:
+            self._close_stage_boundary()
 
     def _phase_gen_update_discr(self, batch, logs):
         self._update_gen()
@@ -242,6 +271,27 @@ class bSSFPToDWITensorModel(nn.Module):
         self._finish_grads("discr")
         self._phase_discr_update()
         self.last_logs = logs
+        return None
+
+    def generator_only_step(self, batch, batch_idx=0):
+        """BASELINE.json configs[1] ("3D U-Net generator only"): generator forward + backward under the L1 loss + AdamW,
+        with the gradient plumbing of ``training_step`` (gradient sinks begin / exchange / finish, no ``zero_grad`` on sink
+        parameters), so that an attached model averages its gradients over the ranks here as well."""
+        x, y = self.unpack_batch(batch)
+        if x.is_cuda:
+            from .functional import DropoutState
+            DropoutState.advance(x.device)
+            if self.enable_grad_sinks():
+                self.sinks_gen.begin_phase(1)
+        loss = self._l1(self.gen(x), y)
+        loss.backward()
+        self._finish_grads("gen")
+        gen_opt, _ = self.optimizers()
+        gen_opt.step()
+        if self.sinks_gen is None:
+            gen_opt.zero_grad()
+        self._repack(self.gen)
+        self.last_logs = {"train_gen_loss_recon_L1": loss.detach()}
         return None
 
     def compute_metrics(self, y_hat, y, step_name, logs=None):
@@ -350,17 +400,22 @@ class GraphedTrainingStep:
     change per replay (device-side step counter), AdamW bias correction advances on the device.
     """
 
-    def __init__(self, model: bSSFPToDWITensorModel, batch, warmup: int = 3, group=None, force_segments: bool = False):
+    def __init__(self, model: bSSFPToDWITensorModel, batch, warmup: int = 3, group=None, force_segments: bool = False,
+                 force_collectives: bool = False, broadcast_buffers_every: int = 0):
         import torch.distributed as dist
         self.model = model
         self.batch = batch
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.segmented = self.world > 1 or force_segments      # (force_segments: the multi-rank structure on one rank, for tests)
+        self.segmented = self.world > 1 or force_segments or force_collectives   # (force_*: the multi-rank structure on one rank)
+        # DDP's broadcast_buffers=True (src/train.py:30): rank 0's BatchNorm running statistics to every rank before every
+        # k-th step (0 = never; the buffers are ~8 KB, the broadcast runs between two graph replays)
+        self.broadcast_buffers_every = broadcast_buffers_every if self.world > 1 else 0
+        self.step_index = 0
         if model.grad_sync_gen is not None or model.grad_sync_discr is not None:
             raise RuntimeError("GraphedTrainingStep does its own gradient exchange: do not ddp.attach() the model")
         if self.segmented:
-            if not model.enable_grad_sinks(group):
+            if not model.enable_grad_sinks(group, distributed=True, force_collectives=force_collectives):
                 raise RuntimeError("GraphedTrainingStep with world size > 1 needs the HIP networks on the GPU")
             model.sinks_gen.auto_launch = model.sinks_discr.auto_launch = False      # launched between the segments
         self.launch_log = []                                # (what, position) of the latest step: tests
@@ -398,6 +453,8 @@ class GraphedTrainingStep:
         """The multi-rank step: ``run(i)`` executes segment i (eagerly or as a graph replay)."""
         m = self.model
         self.launch_log = []
+        m.sinks_gen.launch_order = []
+        m.sinks_discr.launch_order = []
         run(0)
         m.sinks_gen.launch(0); self.launch_log.append(("allreduce gen[0]", "before gen backward stage 2"))
         run(1)
@@ -438,6 +495,10 @@ class GraphedTrainingStep:
                 self.batch[k][DATA].copy_(v[DATA], non_blocking=True)
 
     def __call__(self):
+        if self.broadcast_buffers_every:
+            from . import ddp
+            ddp.broadcast_buffers(self.model, every=self.broadcast_buffers_every, step=self.step_index, group=self.group)
+        self.step_index += 1
         if not self.segmented:
             self.graphs[0].replay()
         else:

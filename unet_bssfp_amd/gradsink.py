@@ -29,13 +29,35 @@ def sink_of(p: Optional[torch.Tensor]):
     return getattr(p, "_mi355_sink", None) if p is not None else None
 
 
+def sink_grad(p: torch.Tensor) -> torch.Tensor:
+    """``p.grad`` of a parameter owned by a GradBuckets object -- the permanent view into its bucket.  A caller that ran
+    ``optimizer.zero_grad()`` (``set_to_none=True`` is torch's default) after the sinks were enabled has dropped that view:
+    fail loudly instead of handing the gradient kernels a null pointer."""
+    g = p.grad
+    if g is None:
+        raise RuntimeError("unet_bssfp_amd: this parameter's gradient lives in a gradient bucket (gradsink.GradBuckets) but "
+                           "its .grad view is gone -- do not call zero_grad() on a model whose gradient sinks are enabled "
+                           "(the buckets are overwritten by the next backward pass; model.use_grad_sinks = False restores "
+                           "plain autograd accumulation)")
+    return g
+
+
 class GradBuckets:
-    def __init__(self, buckets: Sequence[Iterable[torch.nn.Parameter]], group=None, uses_per_phase: int = 1):
+    def __init__(self, buckets: Sequence[Iterable[torch.nn.Parameter]], group=None, uses_per_phase: int = 1,
+                 distributed: bool = False, force_collectives: bool = False):
         """``buckets``: parameter lists in the order their gradients become ready (one flat buffer each);
         ``uses_per_phase``: gradient contributions every parameter receives per backward pass (2 for the discriminator
-        in the discriminator phase: fake and real batch, src/model.py:185-186)."""
+        in the discriminator phase: fake and real batch, src/model.py:185-186).
+        ``distributed``: exchange the buckets over ``group`` (only ``ddp.attach`` and ``GraphedTrainingStep`` turn this
+        on: a model that was never attached must not start collectives just because a process group exists -- its
+        parameters were never broadcast and other ranks may not be training at all).
+        ``force_collectives``: issue the all-reduces even on a one-rank group (rehearsal of the RCCL + hipGraph interplay
+        on a single GPU: ``bench.py --force-collectives``)."""
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.world = dist.get_world_size(group) if (distributed and dist.is_initialized()) else 1
+        self.exchange = self.world > 1 or (force_collectives and distributed and dist.is_initialized())
+        # RCCL averages inside the collective (ncclAvg); gloo has no AVG: sum, then one scale pass (CPU tests only)
+        self._avg = self.exchange and dist.get_backend(group) == "nccl"
         self.uses = uses_per_phase
         self.params: List[List[torch.nn.Parameter]] = []
         self.flat: List[torch.Tensor] = []
@@ -80,7 +102,7 @@ class GradBuckets:
         if self._count[id(p)] == self.uses:
             b = self._where[id(p)]
             self._pending[b] -= 1
-            if self._pending[b] == 0 and self.world > 1 and self.auto_launch:
+            if self._pending[b] == 0 and self.exchange and self.auto_launch:
                 self.launch(b)
 
     # ------------------------------------------------------------------ per-phase control
@@ -99,14 +121,15 @@ class GradBuckets:
         """Sum bucket ``b`` over the ranks, asynchronously: RCCL runs on its own stream and first waits for the
         kernels already enqueued on the current stream (torch.distributed semantics); the backward kernels enqueued
         afterwards overlap it."""
-        if self.world == 1 or self._work[b] is not None:
+        if not self.exchange or self._work[b] is not None:
             return
-        self._work[b] = dist.all_reduce(self.flat[b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        self._work[b] = dist.all_reduce(self.flat[b], op=op, group=self.group, async_op=True)
         self.launch_order.append(b)
 
     def finish(self):
         """Every bucket exchanged and averaged; ``.grad`` views are valid for the optimiser step."""
-        if self.world == 1:
+        if not self.exchange:
             return
         for b in range(len(self.flat)):
             if self._work[b] is None:
@@ -114,7 +137,8 @@ class GradBuckets:
         inv = 1.0 / self.world
         for b, w in enumerate(self._work):
             w.wait()                                  # stream-level wait with nccl, host wait with gloo
-            self.flat[b].mul_(inv)
+            if not self._avg and self.world > 1:
+                self.flat[b].mul_(inv)                # (gloo only: with RCCL the collective itself averages)
             self._work[b] = None
 
     def complete(self) -> bool:
