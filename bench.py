@@ -50,9 +50,9 @@ import torch.distributed as dist  # noqa: E402
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "fp8": 5000.0}
 HBM_PEAK_GBS = 8000.0
 # plan id = 10000*ks + 1000*halo + 100*tile_shape + 10*voxel_subtiles_per_wave + cout_subtiles_per_wave
-PLAN_NAMES = {32041: "conv_march_kernel", 31941: "conv_ru_kernel<1>", 31942: "conv_ru_kernel<2>", 31021: "conv_halo_kernel<float,3,2,4,32,1>",
+PLAN_NAMES = {32041: "conv_march_kernel", 32141: "conv_marchg_kernel<4>", 32121: "conv_marchg_kernel<2>", 31941: "conv_ru_kernel<1>", 31942: "conv_ru_kernel<2>", 31021: "conv_halo_kernel<float,3,2,4,32,1>",
               31022: "conv_halo_kernel<float,3,2,4,32,2>", 31411: "conv_halo_kernel<bf16_t,3,2,4,16,1,4>"}
-KERNEL_SOURCES = ("conv_march.h", "conv_kernels.h", "conv_common.h", "conv_api.hip", "common.h")
+KERNEL_SOURCES = ("conv_march.h", "conv_marchg.h", "conv_kernels.h", "conv_common.h", "conv_api.hip", "common.h")
 
 
 def parse():
@@ -326,7 +326,13 @@ def main():
         local = local % torch.cuda.device_count()        # rehearsal of the multi-rank path on fewer GPUs than ranks (gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    real_stdout = None
     if world > 1 or a.force_collectives:
+        # RCCL ("RCCL version : ...") and gloo ("[Gloo] Rank 0 is connected to ...") print banners on stdout: the contract is
+        # ONE JSON line there, so file descriptor 1 points at stderr for the run and the line is written to the saved one
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:
             os.environ.setdefault("MASTER_PORT", str(a.master_port or free_port()))
@@ -513,7 +519,11 @@ def main():
             out["roofline_hbm"] = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernels": hb, "measured": probe_mode}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.size, a.workload, a.cpu_steps)
-        print(json.dumps(out), flush=True)
+        if real_stdout is not None:
+            sys.stdout.flush()
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        else:
+            print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -108,6 +108,15 @@ CONV_CASES = [
     ("k3_march_n2_short", 2, (32,), 32, (16, 64, 128), 3, 1, 1),    # two samples; last segment is a single plane
     ("k3_march_cin24_cout64", 1, (24,), 64, (32, 64, 128), 3, 1, 1),  # padded input channels, two output-channel blocks
     ("k3_march_long", 1, (32,), 32, (40, 128, 256), 3, 1, 1),       # 11-plane segments: three triples of straight-line steps
+    # more than 32 input channels in whole 32-channel groups, plain output grid, enough footprints x d-segments: the
+    # group-marching kernel (input planes per 32-channel group, weights streamed through an LDS ring) in bf16
+    ("k3_mg_96to32", 1, (32, 64), 32, (40, 64, 128), 3, 1, 1),       # upcat_1.conv_0's shape: skip + up-sampled source
+    ("k3_mg_ragged", 1, (32, 64), 32, (21, 70, 100), 3, 1, 1),       # border footprints in h and w, odd depth
+    ("k3_mg_64to64", 1, (64,), 64, (32, 64, 64), 3, 1, 1),           # 64^3-level shape: two output-channel blocks
+    ("k3_mg_n2_cout96", 2, (64,), 96, (16, 32, 64), 3, 1, 1),        # two samples; 32 -> 96-style data gradient widths
+    ("k3_mg_128to64", 1, (64, 64), 64, (16, 64, 64), 3, 1, 1),       # upcat_2.conv_0: four groups from two sources
+    ("k3_mg_rows2", 1, (64,), 64, (32, 32, 32), 3, 1, 1),            # too few 16-row footprints: the 8-row variant
+    ("k3_mg_256to128", 1, (128, 128), 128, (32, 32, 32), 3, 1, 1),   # upcat_3.conv_0: eight groups, few workgroups, no split-K
     ("k4s2", 1, (30,), 32, (8, 8, 16), 4, 2, 1),
     ("k4s2_ct2", 2, (32,), 64, (8, 8, 8), 4, 2, 1),
     ("k1_head", 2, (24,), 24, (4, 4, 8), 1, 1, 0),
@@ -120,14 +129,14 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", ["march", "ru", "halo"])
+@pytest.mark.parametrize("case", ["march", "marchg", "halo"])
 def test_conv_fused_statistics_with_a_bias_far_from_zero(hip, case):
     """A pre-norm conv bias that has random-walked far from zero (a loaded checkpoint; default init keeps |b| <= 0.04):
     bias = 10 sigma(z - b).  The fused statistics must still be those of (z - b) to f32 summation accuracy -- a kernel that
     accumulates sum z, sum z^2 and subtracts the bias terms afterwards loses ~2 decimal digits of the variance here
     (cancellation of cnt * b^2 against sum z^2); every conv kernel accumulates (z - b) itself."""
     from unet_bssfp_amd import functional as Fn
-    cins, sp, want = {"march": ((32,), (16, 64, 128), 32041), "ru": ((32, 64), (16, 64, 128), None),
+    cins, sp, want = {"march": ((32,), (40, 64, 128), 32041), "marchg": ((32, 64), (16, 64, 128), 32141),
                       "halo": ((64,), (8, 16, 16), None)}[case]
     dtype = torch.bfloat16
     g = torch.Generator().manual_seed(5)
@@ -156,6 +165,16 @@ def test_conv_fused_statistics_with_a_bias_far_from_zero(hip, case):
     assert float(((var_got - var_ref).abs() / var_ref).max()) <= 1e-4, ((var_got - var_ref).abs() / var_ref).max()
     assert float(((s[1, :32] - ref2).abs() / ref2).max()) <= 1e-4
     close(from_act(z, 32), zc + layer.bias.detach().cpu().view(1, -1, 1, 1, 1), dtype, "z")
+
+
+# which kernel a bf16 case must take (plan id = 10000 ks + 1000 halo + 100 shape + 10 vt + ct; mi355_conv_plan_id):
+# 32041 conv_march_kernel, 32141 / 32121 conv_marchg_kernel<4> / <2>, 31941 / 31942 conv_ru_kernel<1> / <2>
+BF16_PLANS = {
+    "k3_march_ragged": 32041, "k3_march_n2_short": 32041, "k3_march_cin24_cout64": 32041, "k3_march_long": 32041,
+    "k3_ru_ct1": 32041, "k3_ru_cout96": 32041, "k3_ru_ragged_concat": 32141, "k3_ru_ct2_n2": 31942,
+    "k3_mg_96to32": 32141, "k3_mg_ragged": 32141, "k3_mg_64to64": 32141, "k3_mg_n2_cout96": 32141, "k3_mg_128to64": 32141,
+    "k3_mg_rows2": 32121, "k3_mg_256to128": 32141,
+}
 
 
 def _conv_layer(cins, cout, ks, stride, pad, seed):
@@ -189,10 +208,8 @@ def test_conv_fwd_bwd(hip, case, dtype):
         z, part = Fn.ConvFn.apply(acts[0], acts[1] if len(acts) > 1 else None, layer.weight, layer.bias, layer.spec, True)
     finally:
         _ops().CONV_PROBE = None
-    if name.startswith("k3_ru") and dtype == torch.bfloat16:
-        assert plans and plans[0] in (31941, 31942, 32041), plans      # conv_ru_kernel<1> / <2> / conv_march_kernel
-    if name.startswith("k3_march") and dtype == torch.bfloat16:
-        assert plans and plans[0] == 32041, plans                      # conv_march_kernel
+    if dtype == torch.bfloat16 and name in BF16_PLANS:
+        assert plans and plans[0] == BF16_PLANS[name], (plans, BF16_PLANS[name])
     close(from_act(z, cout), z_ref.detach(), dtype, "z")
     cp = z.shape[4]
     if cp > cout:                                        # pad channels must hold zeros

@@ -42,9 +42,13 @@ def bench_conv(dtype, reps, only=None):
         bias = layer.bias.detach()
         tiles, _ = ops.conv_num_tiles(x0, x1, wp, coutp, 3, 1, (1, 1, 1), out, (s, s, s))
         part = torch.empty((tiles, 2, coutp), dtype=torch.float32, device=DEV)
+        plan = []
+        ops.CONV_PROBE = lambda pid, d, real: plan.append(pid) and None
+        ops.conv_fwd(x0, x1, wp, coutp, bias, 3, 1, (1, 1, 1), out, (s, s, s), stats=part)
+        ops.CONV_PROBE = None
         ms = timeit(lambda: ops.conv_fwd(x0, x1, wp, coutp, bias, 3, 1, (1, 1, 1), out, (s, s, s), stats=part), reps)
         fl = 2.0 * (c0 + c1) * cout * 27 * s ** 3
-        print(f"conv fwd  {name:28s} {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TFLOP/s")
+        print(f"conv fwd  {name:28s} {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TFLOP/s   plan {plan[0]}  stat rows {tiles}")
 
 
 def bench_deconv(dtype, reps, only=None):

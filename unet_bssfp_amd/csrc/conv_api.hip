@@ -2,6 +2,7 @@
 #include <stdlib.h>
 #include "conv_kernels.h"
 #include "conv_march.h"
+#include "conv_marchg.h"
 
 namespace {
 
@@ -26,6 +27,8 @@ int gcd_i(long long a, long long b) { while (b) { long long t = a % b; a = b; b 
 // 7, 8: retired experiments (row reuse inside conv_halo_kernel with register staging: 216 VGPRs or spills, slower)
 // 9 ru (4x4x32, 4 waves, row-reuse loop, halo by LDS-DMA: conv_ru_kernel)
 // 10 march (16x32 footprint marching along d, 32 input channels resident: conv_march_kernel; tile extents set in make_plan)
+// 11 marchg (4 ROWS x 32 footprint marching along d, input channels in 32-channel groups, weights streamed through an LDS
+//    ring: conv_marchg_kernel<ROWS>; vt = ROWS)
 const int kTD[10] = {2, 2, 4, 4, 2, 2, 4, 8, 4, 4}, kTH[10] = {4, 8, 8, 4, 4, 8, 4, 4, 4, 4}, kTW[10] = {32, 16, 8, 32, 16, 8, 32, 32, 32, 32},
           kVT[10] = {2, 2, 2, 4, 1, 1, 2, 4, 4, 4};
 
@@ -118,6 +121,33 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
             p->nseg = segs;
           }
         }
+        // more than 32 input channels (whole 32-channel groups per source), plain output grid: the group-marching kernel.
+        // Cost model per workgroup: (len + 2) input planes of fixed overhead (three block hand-overs per 32-channel group,
+        // ~900 cycles) + len output planes of MFMA work (54 x 32 cycles per footprint row); ROWS = 4 unless only the
+        // 8-row footprints can fill the chip.
+        const bool marchg_ok = ru_ok && d->dtype == MI355_DT_BF16 && d->c0 % 32 == 0 && d->c1 % 32 == 0 && d->c0 + d->c1 > 32 &&
+                               d->os == 1 && d->ooff[0] == 0 && d->ooff[1] == 0 && d->ooff[2] == 0 &&
+                               d->pad[0] == 1 && d->pad[1] == 1 && d->pad[2] == 1 && d->do_ == d->di && d->ho == d->hi && d->wo == d->wi &&
+                               d->dy == d->do_ && d->hy == d->ho && d->wy == d->wo && (d->cstore & 7) == 0;
+        if (marchg_ok && (f < 0 || f == 11) && pick != 10) {
+          long long best = -1; int best_len = 0, best_rows = 0;
+          for (int rows = 4; rows >= 2; rows -= 2) {
+            const long long fp = (long long)d->n * ceil_div(d->ho, 4 * rows) * ceil_div(d->wo, 32) * (d->coutp / 32);
+            for (int ns = 1; ns <= d->do_ && ns <= 64; ++ns) {
+              const int len = ceil_div(d->do_, ns), segs = ceil_div(d->do_, len);
+              if (fp * segs < 192 && f != 11) continue;     // must fill (most of) the chip
+              const long long rounds = (fp * segs + 255) / 256, cost = rounds * ((len + 2) * 900ll + (long long)len * 1728 * rows);
+              if (best < 0 || cost < best) { best = cost; best_len = len; best_rows = rows; }
+            }
+            if (best >= 0) break;
+          }
+          if (best >= 0) {
+            pick = 11;
+            p->seg_len = best_len;
+            p->nseg = ceil_div(d->do_, best_len);
+            p->vt = best_rows;
+          }
+        }
         p->shape = pick;
       }
       // 32^3-level layers on the plain tile: one 64-channel tile per workgroup leaves <= 1 workgroup per CU on a
@@ -136,6 +166,11 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
       p->tiles_d = p->nseg;
       p->tiles_h = ceil_div(d->ho, kMarchFH);
       p->tiles_w = ceil_div(d->wo, kMarchFW);
+    } else if (p->shape == 11) {
+      p->ct = 1;                                     // (vt = ROWS was set with the plan)
+      p->tiles_d = p->nseg;
+      p->tiles_h = ceil_div(d->ho, 4 * p->vt);
+      p->tiles_w = ceil_div(d->wo, 32);
     } else {
     p->vt = kVT[p->shape];
     p->tiles_d = ceil_div(d->do_, kTD[p->shape]);
@@ -159,7 +194,7 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
   MI355_REQUIRE(p->tiles < (1ll << 31), "conv: too many tiles");
   p->ksplit = 1; p->rpb = 0;
   p->stat_rows = p->tiles; p->stat_rows_per_sample = p->tiles_per_sample;
-  if (p->halo) {
+  if (p->halo && p->shape != 10 && p->shape != 11) {      // (the marching kernels walk the whole contraction themselves)
     // few output positions and a long contraction (8^3 / 16^3 U-Net levels, low PatchGAN levels): the
     // grid cannot fill 256 CUs and every workgroup streams its weights at one L2/HBM latency per tap
     // group => split the contraction over blockIdx.z and combine in a second kernel
@@ -253,6 +288,17 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
           MarchArgs m{p.seg_len, p.nseg, p.tiles_h, p.tiles_w, d->q_amax_x, d->q_amax_w};
           if (d->dtype == MI355_DT_FP8) conv_march_kernel<true><<<grid, block, MarchCfg<true>::LDS, st>>>(a, m);
           else conv_march_kernel<false><<<grid, block, MarchCfg<false>::LDS, st>>>(a, m);
+        }
+      } else if (p.shape == 11) {
+        if constexpr (sizeof(T) == 2) {
+          static const int once = [] {
+            (void)hipFuncSetAttribute((const void*)conv_marchg_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, MarchGCfg<4>::LDS);
+            return (int)hipFuncSetAttribute((const void*)conv_marchg_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, MarchGCfg<2>::LDS);
+          }();
+          (void)once;
+          MarchArgs m{p.seg_len, p.nseg, p.tiles_h, p.tiles_w, nullptr, nullptr};
+          if (p.vt == 4) conv_marchg_kernel<4><<<grid, block, MarchGCfg<4>::LDS, st>>>(a, m);
+          else conv_marchg_kernel<2><<<grid, block, MarchGCfg<2>::LDS, st>>>(a, m);
         }
       } else if (p.shape == 9) {
         if constexpr (sizeof(T) == 2) {

@@ -295,44 +295,69 @@ __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, co
   //      kd = 2 completes (buffer stores: lanes that must not store get an out-of-range offset, no branch).
   const auto rsy = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (int)((((long long)a.n * a.dy * a.hy * a.wy - 1) * a.ldy + a.cstore) * 2), 0x00020000);
   const int yrow = ((4 * wave) * a.wy + w0 + r) * a.ldy * 2 + cch * 2;        // byte offset of this lane's voxel in row 0 of a plane's footprint
+  // The next plane's NI copies are issued ONE AT A TIME between the fragment groups (fenced: nothing is scheduled across a
+  // copy): issued together at the top of the step they cost the wave their whole issue time with the matrix pipe idle; behind
+  // a group, a copy's issue runs under the MFMA in flight.  The table entry of a copy is read one group ahead.  The finished
+  // plane's four rows are converted and stored one per group (groups NG .. NG + 3).
   auto full_step = [&](int p, f32x16 (&s_m1)[4], f32x16 (&s_0)[4], f32x16 (&s_p1)[4]) __attribute__((always_inline)) {
-#ifndef MARCH_DIAG_NO_DMA
-    load_plane(p + 1);
-#endif
+    constexpr int NGR = 3 * NG;
     const char* pl = smem + (p & 1) * Cfg::PLANE;
+    const bool pin = p + 1 >= 0 && p + 1 < a.di;
+    const int soff = pin ? (tn * a.di + p + 1) * plane_stride : 0;
+    char* const dst = smem + ((p + 1) & 1) * Cfg::PLANE + wave * 1024;
+    const int ybase = ((tn * a.dy + (p - 1)) * a.hy + h0) * a.wy * a.ldy * 2;
     Group g[2];
     load_group(g[0], pl, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+    int e_next = vtab[0];
 #pragma unroll
-    for (int gi = 0; gi < 3 * NG; ++gi) {
-      if (gi + 1 < 3 * NG) load_group(g[(gi + 1) & 1], pl, 2 - (gi + 1) / NG, (gi + 1) % NG);
+    for (int gi = 0; gi < NGR; ++gi) {
+      // copy ticket i goes behind group (i * NGR) / NI
+      int ticket = -1;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) if ((i * NGR) / NI == gi) ticket = i;
+      const int e_cur = e_next;
+      if (ticket >= 0 && ticket + 1 < NI) e_next = vtab[(ticket + 1) * 256];
+      if (gi + 1 < NGR) load_group(g[(gi + 1) & 1], pl, 2 - (gi + 1) / NG, (gi + 1) % NG);
       if (gi < NG) mma_group(g[gi & 1], s_m1, false);
       else if (gi < 2 * NG) mma_group(g[gi & 1], s_0, false);
       else mma_group(g[gi & 1], s_p1, gi == 2 * NG);
 #ifdef MARCH_DIAG_NO_STORE
-      if (gi == NG - 1) asm volatile("" :: "v"(s_m1[0][0]), "v"(s_m1[1][5]), "v"(s_m1[2][9]), "v"(s_m1[3][15]));
+      if (gi == NG) asm volatile("" :: "v"(s_m1[0][0]), "v"(s_m1[1][5]), "v"(s_m1[2][9]), "v"(s_m1[3][15]));
 #else
-      if (gi == NG - 1) {                                             // output plane p - 1 is complete
-        const int ybase = ((tn * a.dy + (p - 1)) * a.hy + h0) * a.wy * a.ldy * 2;
-#pragma unroll
-        for (int row = 0; row < 4; ++row) {
-          typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-          uint32_t w[8];
-#ifdef MARCH_EPI_FENCE
-          __builtin_amdgcn_sched_barrier(MARCH_EPI_FENCE);
+      if (gi >= NG && gi < NG + 4) {                                    // output plane p - 1 is complete: row gi - NG
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const int row = gi - NG;
+        uint32_t w[8];
+        pack_row(s_m1[row], w, true);
+        // (the plane's base goes into the VECTOR offset, soffset = 0: with a register soffset hipcc places a VALU write
+        //  of the store's data registers right behind a 16-byte store -- on gfx950 the store then read the NEW values
+        //  in its last lanes; with a constant soffset the compiler's own hazard rule keeps the wait state)
+        const int off = ybase + yrow + row * a.wy * a.ldy * 2;
+        u32x4 lo = {w[0], w[1], w[2], w[3]}, hi = {w[4], w[5], w[6], w[7]};
+        __builtin_amdgcn_raw_buffer_store_b128(lo, rsy, st0 ? off : (int)0x80000000, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(hi, rsy, st1 ? off + 16 : (int)0x80000000, 0, 0);
+      }
 #endif
-          pack_row(s_m1[row], w, true);
-          // (the plane's base goes into the VECTOR offset, soffset = 0: with a register soffset hipcc places a VALU write
-          //  of the store's data registers right behind a 16-byte store -- on gfx950 the store then read the NEW values
-          //  in its last lanes; with a constant soffset the compiler's own hazard rule keeps the wait state)
-          const int off = ybase + yrow + row * a.wy * a.ldy * 2;
-          u32x4 lo = {w[0], w[1], w[2], w[3]}, hi = {w[4], w[5], w[6], w[7]};
-          __builtin_amdgcn_raw_buffer_store_b128(lo, rsy, st0 ? off : (int)0x80000000, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(hi, rsy, st1 ? off + 16 : (int)0x80000000, 0, 0);
+      // this group's MFMAs with the next group's reads between them (see pin_pipeline)
+#pragma unroll
+      for (int k = 0; k < NMM; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (gi + 1 < NGR) {
+          if constexpr (F8) {
+            if (k < 2) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          } else if (k < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
+      }
+#ifndef MARCH_DIAG_NO_DMA
+      if (ticket >= 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        dma_lds_b128(rsx, dst + ticket * 4096, (pin && e_cur >= 0) ? e_cur : (int)0x80000000, soff);
+        __builtin_amdgcn_sched_barrier(0);
       }
 #endif
     }
-    pin_pipeline(3 * NG);
 #ifndef MARCH_DIAG_NO_WAIT
     dma_wait_all();
 #endif
