@@ -369,13 +369,21 @@ __global__ __launch_bounds__(256, 1) void conv_marchg_kernel(const ConvArgs a, c
   {
     f32x16 acc[3][ROWS];
     zero_set(acc[0]); zero_set(acc[1]); zero_set(acc[2]);
-    // input planes d0 - 1 .. d1, padded to a multiple of three with planes past the segment (their blocks do not run, their
-    // copies are zero-fills): the rotation of the three register sets then needs no control flow between the planes --
-    // with `if (p > d1) skip` joins hipcc copied and spilled whole 64-register sets at every join.
-    for (int pb = d0 - 1; pb <= d1; pb += 3) {
+    // input planes d0 - 1 .. d1 in triples (the rotation of the three register sets returns to its start after three planes,
+    // so the loop body needs no control flow between the planes -- with `if (p > d1) skip` joins inside the loop hipcc
+    // copied and spilled whole 64-register sets); the one or two planes left over run behind the loop, nested, where no
+    // accumulator is live across a join.
+    const int np = d1 - d0 + 2;
+    int pb = d0 - 1;
+    for (int t3 = 0; t3 < np / 3; ++t3) {
       plane(pb, acc[2], acc[0], acc[1]);
       plane(pb + 1, acc[0], acc[1], acc[2]);
       plane(pb + 2, acc[1], acc[2], acc[0]);
+      pb += 3;
+    }
+    if (np % 3 >= 1) {
+      plane(pb, acc[2], acc[0], acc[1]);
+      if (np % 3 == 2) plane(pb + 1, acc[0], acc[1], acc[2]);
     }
   }
   dma_wait_all();

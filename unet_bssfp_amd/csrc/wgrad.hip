@@ -454,9 +454,12 @@ constexpr int wm_row_reads(int half, int y) {
   return n;
 }
 
-// one plane of one wave
-template <int HALF>
-__device__ __forceinline__ void wm_plane(f32x16 (&acc)[5][3], const char* xs, const char* gp, const int p, const int seg_lane_off) {
+// one plane of one wave.  between(y): called behind halo row y's MFMAs, fenced (nothing is scheduled across it): the
+// step's copy tickets, one per row -- issued together at the top of the step, the 10 copies cost the wave their whole issue
+// time with the matrix pipe idle; behind a row, a copy's issue runs under the MFMA in flight (conv_march.h).
+template <int HALF, typename Between>
+__device__ __forceinline__ void wm_plane(f32x16 (&acc)[5][3], const char* xs, const char* gp, const int p, const int seg_lane_off,
+                                         Between between) {
   bf16x8 gf[kWmFH];
 #pragma unroll
   for (int sh = 0; sh < kWmFH; ++sh) gf[sh] = frag_tr(gp + sh * (kWmFW * 64));
@@ -470,6 +473,9 @@ __device__ __forceinline__ void wm_plane(f32x16 (&acc)[5][3], const char* xs, co
 #pragma unroll
   for (int i = 0; i < 5; ++i)
     if (wm_need(HALF, i, 0)) xf[0][i] = frag_tr(xb[i]);
+  // order: the g fragments and halo row 0, then per halo row its MFMAs with the next row's reads spread between them
+  // (one wave per SIMD: nothing else hides the LDS latency, and hipcc would sink every read next to its first use)
+  __builtin_amdgcn_sched_group_barrier(0x100, 2 * kWmFH + wm_row_reads(HALF, 0), 0);
 #pragma unroll
   for (int y = 0; y < kWmHR; ++y) {
 #pragma unroll
@@ -481,12 +487,6 @@ __device__ __forceinline__ void wm_plane(f32x16 (&acc)[5][3], const char* xs, co
       for (int kh = 0; kh < 3; ++kh)
         if (wm_valid(HALF, i, y, kh))
           acc[i][kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[y & 1][i], gf[y - kh], acc[i][kh], 0, 0, 0);
-  }
-  // order: the g fragments and halo row 0, then per halo row its MFMAs with the next row's reads spread between them
-  // (one wave per SIMD: nothing else hides the LDS latency, and hipcc would sink every read next to its first use)
-  __builtin_amdgcn_sched_group_barrier(0x100, 2 * kWmFH + wm_row_reads(HALF, 0), 0);
-#pragma unroll
-  for (int y = 0; y < kWmHR; ++y) {
     const int M = wm_row_mfmas(HALF, y), R = wm_row_reads(HALF, y + 1);
 #pragma unroll
     for (int k = 0; k < M; ++k) {
@@ -496,6 +496,9 @@ __device__ __forceinline__ void wm_plane(f32x16 (&acc)[5][3], const char* xs, co
       else if (nr == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       else if (nr == 3) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    between(y);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -596,13 +599,28 @@ __global__ __launch_bounds__(256, 1) void wgrad_march_kernel(const WgradArgs a, 
   // shuffle the 240 accumulator registers); every wave passes the same number of barriers
   auto march = [&](auto halfc) __attribute__((always_inline)) {
     for (int p = d0; p < d1; ++p) {
+      // every step issues the same number of copies (past the segment: zeros into free slots), so that "all but the newest
+      // kWmPerStep" is the wait for the copies of the step before; ticket y goes behind halo row y: x plane p + 3 (rows
+      // 0 .. 5), g plane p + 2 (rows 6 .. 9)
+      const int qx = p + 3, pg = p + 2;
+      const bool pinx = qx >= 0 && qx < a.di, ping = pg < d1;
+      const int soffx = pinx ? (tn * a.di + qx) * xplane : 0, soffg = ping ? (tn * a.gd + pg) * gplane : 0;
+      const int killx = pinx ? 0 : (int)0x80000000, killg = ping ? 0 : (int)0x80000000;
+      char* const dstx = xs + ((unsigned)(qx + 1) % kWmXR) * kWmXS + wave * 1024;
+      char* const dstg = gsm + ((unsigned)pg % kWmGR) * kWmGS + wave * 1024;
+      auto ticket = [&](const int y) __attribute__((always_inline)) {
 #ifndef WM_DIAG_NO_DMA
-      load_x(p + 3);              // every step issues the same number of copies (past the segment: zeros into free slots),
-      load_g(p + 2);              // so that "all but the newest kWmPerStep" is the wait for the copies of the step before
+        static_assert(kWmXI / 4 + kWmGI / 4 == kWmHR, "one copy ticket per halo row");
+        if (y < kWmXI / 4) dma_lds_b128(rsx, (y == 5 && wave >= 2) ? dump + (wave - 2) * 1024 : dstx + y * 4096, xoff[y] | killx, soffx);
+        else dma_lds_b128(rsg, dstg + (y - kWmXI / 4) * 4096, goff[y - kWmXI / 4] | killg, soffg);
 #endif
+      };
       const char* gp = gsm + ((unsigned)p % kWmGR) * kWmGS + seg_lane_off;
 #ifndef WM_DIAG_NO_MMA
-      wm_plane<decltype(halfc)::value>(acc, xs, gp, p, seg_lane_off);
+      wm_plane<decltype(halfc)::value>(acc, xs, gp, p, seg_lane_off, ticket);
+#else
+#pragma unroll
+      for (int y = 0; y < kWmHR; ++y) ticket(y);
 #endif
 #ifndef WM_DIAG_NO_WAIT
       asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kWmPerStep) : "memory");   // x plane p + 2, g plane p + 1 have landed (this wave's share) ...
