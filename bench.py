@@ -73,6 +73,10 @@ def parse():
                     help="torch.distributed backend at world size > 1 (nccl = RCCL; gloo: rehearsal of the multi-rank path, ranks may share a GPU)")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of as hipGraph replays")
     ap.add_argument("--fresh-batch", action="store_true", help="a new host batch every step (H2D hidden on a side stream)")
+    ap.add_argument("--fresh-copy-after", type=int, default=None,
+                    help="with --fresh-batch: run the step as its five graph segments and start the next batch's copy behind segment k (0..3)")
+    ap.add_argument("--fresh-diag", default=None, choices=["h2d", "d2d", "nowait_ready", "nowait_consumed", "nowait_both"],
+                    help="developer: with --fresh-batch, only the host-to-device copies (inputs stay stale) or only the device-to-device swap")
     ap.add_argument("--force-collectives", action="store_true",
                     help="one rank, real process group: run the FIVE-segment graph step and issue its four all-reduces "
                          "(rehearsal of process group + watchdog + thread-local capture on a single GPU)")
@@ -250,44 +254,79 @@ def profiled_traffic(kernel, dtype, size, workload, batch):
 
 
 class FreshBatches:
-    """A new host batch per step: pinned host double buffer -> device staging buffer on a side stream (overlaps the
-    running step) -> device-to-device copy into the graph's static input tensors at the step boundary."""
+    """A new host batch per step (src/data_module.py:185-188 delivers one every step) without a staging buffer: the step is
+    captured over TWO static input sets (GraphedTrainingStep.add_instance) and runs on them alternately; while instance k
+    replays, the next host batch crosses PCIe on a side stream straight into the inputs of instance 1 - k, which finished its
+    last replay before instance k started.  No device-to-device copy at the step boundary, and the only cross-stream waits are
+    on events that completed a whole step earlier."""
 
     def __init__(self, gstep, nbuf=2):
         self.gstep = gstep
         self.stream = torch.cuda.Stream()
-        self.keys = [(k, v["data"]) for k, v in gstep.batch.items() if isinstance(v, dict) and "data" in v]
-        uniq, seen = [], set()
-        for k, t in self.keys:                                   # 'dwi-tensor' and 'dwi-tensor_orig' share one tensor
-            if t.data_ptr() not in seen:
-                seen.add(t.data_ptr())
-                uniq.append((k, t))
-        self.keys = uniq
+        first = gstep.batch
+        second = {}
+        cache = {}
+        for k, v in first.items():                               # 'dwi-tensor' and 'dwi-tensor_orig' share one tensor
+            if isinstance(v, dict) and "data" in v:
+                t = v["data"]
+                if t.data_ptr() not in cache:
+                    cache[t.data_ptr()] = t.clone()
+                second[k] = {"data": cache[t.data_ptr()]}
+            else:
+                second[k] = v
+        gstep.add_instance(second)
+        self.sets = []
+        for b in (first, second):
+            uniq, seen = [], set()
+            for k, v in b.items():
+                if isinstance(v, dict) and "data" in v and v["data"].data_ptr() not in seen:
+                    seen.add(v["data"].data_ptr())
+                    uniq.append(v["data"])
+            self.sets.append(uniq)
         g = torch.Generator().manual_seed(4321)
-        self.host = [[torch.rand(t.shape, generator=g).pin_memory() for _, t in self.keys] for _ in range(nbuf)]
-        self.staging = [torch.empty_like(t) for _, t in self.keys]
-        self.ready = torch.cuda.Event()
-        self.consumed = torch.cuda.Event()
-        self.consumed.record()
+        self.host = [[torch.rand(t.shape, generator=g).pin_memory() for t in self.sets[0]] for _ in range(nbuf)]
+        self.ready = [torch.cuda.Event(), torch.cuda.Event()]    # the host batch has landed in input set k
+        self.done = [torch.cuda.Event(), torch.cuda.Event()]     # the latest replay over input set k has finished
+        cur = torch.cuda.current_stream()
+        for k in (0, 1):
+            self.done[k].record(cur)
         self.i = 0
-        self.prefetch()
+        self.diag = None
+        self.mark = torch.cuda.Event()
+        self._copy_into(0)                                       # the first step's batch
 
-    def prefetch(self):
+    copy_after = None                                            # segment index behind which the next batch's copy starts
+
+    def _copy_into(self, k, also_wait=None):
         with torch.cuda.stream(self.stream):
-            self.stream.wait_event(self.consumed)                # the staging buffer has been copied out
-            for s, h in zip(self.staging, self.host[self.i % len(self.host)]):
-                s.copy_(h, non_blocking=True)
-            self.ready.record(self.stream)
+            if also_wait is not None:
+                self.stream.wait_event(also_wait)
+            if self.diag not in ("nowait_consumed", "nowait_both"):
+                self.stream.wait_event(self.done[k])             # input set k is no longer being read
+            for t, h in zip(self.sets[k], self.host[self.i % len(self.host)]):
+                t.copy_(h, non_blocking=True)
+            self.ready[k].record(self.stream)
         self.i += 1
 
-    def swap_in(self):
+    def step(self, i):
+        k = i & 1
         cur = torch.cuda.current_stream()
-        cur.wait_event(self.ready)
-        for (_, t), s in zip(self.keys, self.staging):
-            t.copy_(s, non_blocking=True)
-        self.consumed.record(cur)
-        # the caller launches the step FIRST and then calls prefetch(): enqueueing a 250 MB host-to-device copy can hold
-        # the CPU thread for milliseconds, which must pass while the GPU is busy with the step, not in front of it
+        if self.diag not in ("nowait_ready", "nowait_both"):
+            cur.wait_event(self.ready[k])
+        if self.copy_after is None:
+            self.gstep(k)
+            self.done[k].record(cur)
+            # (after the launch: enqueueing a 250 MB host-to-device copy can hold the CPU thread for milliseconds, which
+            #  must pass while the GPU is busy with the step, not in front of it)
+            self._copy_into(1 - k)
+        else:
+            # segmented step: the copy starts once segment `copy_after` of THIS step has run (an event on the main stream)
+            def after(seg):
+                if seg == self.copy_after:
+                    self.mark.record(cur)
+                    self._copy_into(1 - k, also_wait=self.mark)
+            self.gstep(k, after)
+            self.done[k].record(cur)
 
 
 def free_port() -> int:
@@ -347,6 +386,10 @@ def main():
         nondefault["backend"] = a.backend
     if a.force_collectives:
         nondefault["force_collectives"] = True
+    if a.fresh_diag:
+        nondefault["fresh_diag"] = a.fresh_diag
+    if a.fresh_copy_after is not None:
+        nondefault["fresh_copy_after"] = a.fresh_copy_after
     if a.lib:
         from tools import diaglib
         nondefault["lib"] = diaglib.use(a.lib)
@@ -381,16 +424,18 @@ def main():
             ddp.broadcast_module_state(model.discr, 0)
         # 2 eager steps (allocations, caches, optimiser state) + capture
         gstep = GraphedTrainingStep(model, batch, warmup=2, force_collectives=a.force_collectives,
+                                    force_segments=a.fresh_batch and a.fresh_copy_after is not None,
                                     broadcast_buffers_every=a.bn_broadcast_every)
         if a.fresh_batch:
             fresh = FreshBatches(gstep)
+            fresh.diag = a.fresh_diag
+            fresh.copy_after = a.fresh_copy_after
 
         def step(i):
             if fresh is not None:
-                fresh.swap_in()
-            gstep()
-            if fresh is not None:
-                fresh.prefetch()                                 # next batch crosses PCIe under this step
+                fresh.step(i)
+            else:
+                gstep()
         mode = "hipgraph"
     else:
         if world > 1:
@@ -480,7 +525,7 @@ def main():
                        "dropout": a.dropout, "perceptual_term": "absent (needs remote weights)",
                        "parallelism": f"dp{world}",
                        "bn_buffer_broadcast_every": (a.bn_broadcast_every if world > 1 else None),
-                       "input_feed": "new host batch every step, H2D on a side stream" if fresh is not None else "one batch resident in HBM"},
+                       "input_feed": "new host batch every step: host-to-device copy on a side stream into the idle one of two static input sets" if fresh is not None else "one batch resident in HBM"},
             "step_tflops": flop_per_vol * vols / dt / 1e12,
             "launch_mode": mode,
             "timed_region_s": dt, "settle_steps": settle_steps,

@@ -525,6 +525,48 @@ def test_hipgraph_replayed_step_equals_eager_step(hip):
     assert g_opt.state[graphed.gen.blocks["unet"].final_conv.weight]["step"] == 4
 
 
+def test_hipgraph_two_input_sets_equal_eager_steps_on_alternating_batches(hip):
+    """GraphedTrainingStep.add_instance: the step captured over a second static input set (the feed of
+    src/data_module.py:185-188 -- a new batch every step -- alternates between the two sets instead of copying into one):
+    replays 0, 1, 0, 1 over batches A, B must equal eager training steps on A, B, A, B bit for bit."""
+    import unet_bssfp_amd as M
+    from unet_bssfp_amd.functional import DropoutState
+    from unet_bssfp_amd.gan import GraphedTrainingStep, bSSFPToDWITensorModel, synthetic_batch
+
+    def build():
+        torch.manual_seed(4)
+        DropoutState.reset()
+        gen, discr = M.Generator("bssfp", dropout=0.05), M.Discriminator("bssfp")
+        return bSSFPToDWITensorModel("bssfp", gen=gen.to(DEV), discr=discr.to(DEV)).train()
+
+    a, b = synthetic_batch(2, 32, seed=9, device=DEV), synthetic_batch(2, 32, seed=10, device=DEV)
+    c = synthetic_batch(2, 32, seed=11, device=DEV)
+    # the eager model runs first and is snapshotted: build() resets the process-wide dropout counter, which a model that is
+    # still stepping must not lose
+    eager = build()
+    snaps = []
+    for i, batch in enumerate((a, a, a, b, a, b, c)):         # two warm-up steps on A (as the graphed model), then A B A B, then C
+        eager.training_step(batch, i)
+        if i in (5, 6):
+            torch.cuda.synchronize()
+            snaps.append([p.detach().clone() for p in eager.parameters()])
+    graphed = build()
+    gs = GraphedTrainingStep(graphed, a, warmup=2)
+    assert gs.add_instance(b) == 1
+    for k in (0, 1, 0, 1):
+        gs(k)
+    torch.cuda.synchronize()
+    for (n, q), p in zip(graphed.named_parameters(), snaps[0]):
+        assert torch.equal(p, q), n
+    # new data written into an input set between replays is what the next replay of that set trains on
+    for key in ("bssfp", "dwi-tensor_orig"):
+        a[key]["data"].copy_(c[key]["data"])
+    gs(0)
+    torch.cuda.synchronize()
+    for (n, q), p in zip(graphed.named_parameters(), snaps[1]):
+        assert torch.equal(p, q), n
+
+
 def test_gradient_sinks_equal_autograd_accumulation(hip):
     """gradsink.GradBuckets (gradient kernels write parameter gradients in place, second uses accumulate in the kernel) must
     give the same gradients and the same parameters after two steps as plain autograd accumulation (.grad tensors created by

@@ -422,36 +422,58 @@ class GraphedTrainingStep:
         for _ in range(max(2, warmup)):                     # eager: allocations, caches, optimiser state
             self._eager_step()
         torch.cuda.synchronize()
-        self.graphs = []
         self.logs: Dict[str, torch.Tensor] = {}
-        logs = self.logs
+        self.graphs = self._capture(batch, None)
+        # further instances of the SAME step over other static input sets (``add_instance``): a feed that alternates between two
+        # sets copies the next host batch straight into the set that is not running -- no staging buffer, no device-to-device
+        # copy at the step boundary (bench.py --fresh-batch; src/data_module.py:185-188 delivers a new batch every step)
+        self.instances = [(batch, self.graphs)]
+        model.last_logs = self.logs
+        torch.cuda.synchronize()
+
+    def _capture(self, batch, pool):
+        model, logs = self.model, self.logs
         if not self.segmented:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
+            with torch.cuda.graph(g, pool=pool, capture_error_mode=CAPTURE_MODE):
                 model._phase_gen(batch, logs)
                 model._phase_gen_update_discr(batch, logs)
                 model._phase_discr_update()
-            self.graphs = [g]
-        else:
-            gs = [torch.cuda.CUDAGraph() for _ in range(5)]
-            with torch.cuda.graph(gs[0], capture_error_mode=CAPTURE_MODE):
-                model._phase_gen(batch, logs, staged=True)
-            with torch.cuda.graph(gs[1], pool=gs[0].pool(), capture_error_mode=CAPTURE_MODE):
-                model._backward_early()
-            with torch.cuda.graph(gs[2], pool=gs[0].pool(), capture_error_mode=CAPTURE_MODE):
-                model._update_gen()
-                model._phase_discr(batch, logs, staged=True)
-            with torch.cuda.graph(gs[3], pool=gs[0].pool(), capture_error_mode=CAPTURE_MODE):
-                model._backward_early()
-            with torch.cuda.graph(gs[4], pool=gs[0].pool(), capture_error_mode=CAPTURE_MODE):
-                model._phase_discr_update()
-            self.graphs = gs
-        model.last_logs = logs
-        torch.cuda.synchronize()
+            return [g]
+        gs = [torch.cuda.CUDAGraph() for _ in range(5)]
+        with torch.cuda.graph(gs[0], pool=pool, capture_error_mode=CAPTURE_MODE):
+            model._phase_gen(batch, logs, staged=True)
+        pool = gs[0].pool() if pool is None else pool
+        with torch.cuda.graph(gs[1], pool=pool, capture_error_mode=CAPTURE_MODE):
+            model._backward_early()
+        with torch.cuda.graph(gs[2], pool=pool, capture_error_mode=CAPTURE_MODE):
+            model._update_gen()
+            model._phase_discr(batch, logs, staged=True)
+        with torch.cuda.graph(gs[3], pool=pool, capture_error_mode=CAPTURE_MODE):
+            model._backward_early()
+        with torch.cuda.graph(gs[4], pool=pool, capture_error_mode=CAPTURE_MODE):
+            model._phase_discr_update()
+        return gs
 
-    def _segments(self, run):
-        """The multi-rank step: ``run(i)`` executes segment i (eagerly or as a graph replay)."""
+    def add_instance(self, batch) -> int:
+        """Capture the step once more over another static input set (same shapes); the instances share one memory pool, so
+        they must never run concurrently -- they do not: one stream, one replay at a time.  Returns the instance index for
+        ``__call__(instance)``."""
+        torch.cuda.synchronize()
+        graphs = self._capture(batch, self.graphs[0].pool())
+        self.instances.append((batch, graphs))
+        torch.cuda.synchronize()
+        return len(self.instances) - 1
+
+    def _segments(self, run_segment, after=None):
+        """The multi-rank step: ``run(i)`` executes segment i (eagerly or as a graph replay); ``after(i)`` (optional) is
+        called on the host right after segment i has been enqueued (input feeds hook their copies in here)."""
         m = self.model
+
+        def run(i):
+            run_segment(i)
+            if after is not None:
+                after(i)
         self.launch_log = []
         m.sinks_gen.launch_order = []
         m.sinks_discr.launch_order = []
@@ -494,15 +516,18 @@ class GraphedTrainingStep:
             if k in self.batch and isinstance(v, dict) and DATA in v:
                 self.batch[k][DATA].copy_(v[DATA], non_blocking=True)
 
-    def __call__(self):
+    def __call__(self, instance: int = 0, after=None):
         if self.broadcast_buffers_every:
             from . import ddp
             ddp.broadcast_buffers(self.model, every=self.broadcast_buffers_every, step=self.step_index, group=self.group)
         self.step_index += 1
+        graphs = self.instances[instance][1]
         if not self.segmented:
-            self.graphs[0].replay()
+            graphs[0].replay()
+            if after is not None:
+                after(0)
         else:
-            self._segments(lambda i: self.graphs[i].replay())
+            self._segments(lambda i: graphs[i].replay(), after)
         self.model.last_logs = self.logs
 
 
