@@ -75,8 +75,8 @@ def parse():
     ap.add_argument("--fresh-batch", action="store_true", help="a new host batch every step (H2D hidden on a side stream)")
     ap.add_argument("--fresh-copy-after", type=int, default=None,
                     help="with --fresh-batch: run the step as its five graph segments and start the next batch's copy behind segment k (0..3)")
-    ap.add_argument("--fresh-diag", default=None, choices=["h2d", "d2d", "nowait_ready", "nowait_consumed", "nowait_both"],
-                    help="developer: with --fresh-batch, only the host-to-device copies (inputs stay stale) or only the device-to-device swap")
+    ap.add_argument("--fresh-diag", default=None, choices=["nowait_ready", "nowait_done", "nowait_both", "x_only", "y_only", "gpu_wait"],
+                    help="developer, timing only: --fresh-batch without one of its stream waits, or copying only x (201 MB) / only y (50 MB)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="one rank, real process group: run the FIVE-segment graph step and issue its four all-reduces "
                          "(rehearsal of process group + watchdog + thread-local capture on a single GPU)")
@@ -301,9 +301,16 @@ class FreshBatches:
         with torch.cuda.stream(self.stream):
             if also_wait is not None:
                 self.stream.wait_event(also_wait)
-            if self.diag not in ("nowait_consumed", "nowait_both"):
-                self.stream.wait_event(self.done[k])             # input set k is no longer being read
-            for t, h in zip(self.sets[k], self.host[self.i % len(self.host)]):
+            # input set k must no longer be read: its last replay has FINISHED.  The host waits for that (it is one step ahead
+            # of the GPU and has nothing else to do); a GPU-side wait of the copy stream on an event recorded between two
+            # graph launches cost ~0.65 ms per step whatever the copy's size (measured: --fresh-diag gpu_wait)
+            if self.diag == "gpu_wait":
+                self.stream.wait_event(self.done[k])
+            elif self.diag not in ("nowait_done", "nowait_both"):
+                self.done[k].synchronize()
+            for j, (t, h) in enumerate(zip(self.sets[k], self.host[self.i % len(self.host)])):
+                if (self.diag == "x_only" and j != 0) or (self.diag == "y_only" and j == 0):
+                    continue                                     # (timing-only: how does the cost scale with the bytes copied?)
                 t.copy_(h, non_blocking=True)
             self.ready[k].record(self.stream)
         self.i += 1
