@@ -84,6 +84,8 @@ def parse():
                     help="world size > 1: broadcast rank 0's BatchNorm running statistics before every k-th step "
                          "(DDP's broadcast_buffers=True, src/train.py:30; 0 = never)")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch (--gpus N without torch.distributed.run): rendezvous port (0 = pick a free one)")
+    ap.add_argument("--small-norm-elements", type=int, default=None,
+                    help="developer A/B: size limit of the one-launch norm kernels (0 = off); reported")
     ap.add_argument("--lib", default=None, help="developer A/B: another build of the C ABI (tools/diaglib.py); reported")
     return ap.parse_args()
 
@@ -405,6 +407,9 @@ def main():
     from unet_bssfp_amd import ddp, ops
     from unet_bssfp_amd.gan import bSSFPToDWITensorModel, synthetic_batch
 
+    if a.small_norm_elements is not None:
+        ops.SMALL_NORM_ELEMENTS = a.small_norm_elements
+        nondefault["small_norm_elements"] = a.small_norm_elements
     dtype = M.compute_dtype_from_name(a.dtype)
     torch.manual_seed(0)                                   # identical init on every rank
     gen = M.Generator("bssfp", dropout=a.dropout)

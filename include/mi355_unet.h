@@ -252,6 +252,23 @@ int mi355_normact_bwd_finalize_into(const float* part, int32_t blocks_per_group,
                                     void* stream);
 int mi355_normact_bwd_apply(const mi355_normact_desc* d, void* stream);
 
+/* Norm + dropout + LeakyReLU of a SMALL tensor (the 16^3 / 8^3 U-Net levels, the last PatchGAN blocks: src/model.py:22-28,
+ * 79-82) as ONE launch each way: a workgroup owns 16 bytes of channels of every row, computes the statistics itself
+ * (mean, then variance about it) and applies them -- no statistics from the convolution, no finalize launch.
+ * fwd: writes a, mean_out / rstd_out [groups][c] (kept for the backward pass) and, for BatchNorm in training mode, the running
+ * statistics (momentum update with the unbiased variance, groups in order) and batches_tracked += groups.
+ * bwd: base.mean / base.rstd = what fwd wrote; writes dz and the affine gradients (first n_affine channels; `accumulate`
+ * adds to what is there).  base.part / base.sums / base.blocks_per_group are unused. */
+typedef struct mi355_normact_small_desc {
+  mi355_normact_desc base;
+  float eps, momentum;
+  float* mean_out; float* rstd_out;
+  float* running_mean; float* running_var; int64_t* batches_tracked; int32_t n_real;
+  float* dgamma; float* dbeta; int32_t accumulate;
+} mi355_normact_small_desc;
+int mi355_normact_small_fwd(const mi355_normact_small_desc* d, void* stream);
+int mi355_normact_small_bwd(const mi355_normact_small_desc* d, void* stream);
+
 /* per-channel sum over all rows (bias gradient of a conv without normalisation):
  * out[c] = sum_rows x[row][c] from channel_stats partials (parts x [2][c]) */
 int mi355_colsum_finalize(const float* part, int32_t parts, int32_t c, float* out, void* stream);

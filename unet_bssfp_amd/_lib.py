@@ -59,6 +59,12 @@ class NormActDesc(C.Structure):
                 ("n_affine", _i32)]
 
 
+class NormSmallDesc(C.Structure):
+    _fields_ = [("base", NormActDesc), ("eps", _f32), ("momentum", _f32), ("mean_out", _vp), ("rstd_out", _vp),
+                ("running_mean", _vp), ("running_var", _vp), ("batches_tracked", _vp), ("n_real", _i32),
+                ("dgamma", _vp), ("dbeta", _vp), ("accumulate", _i32)]
+
+
 _SIGNATURES = {
     "mi355_version": (C.c_int, []),
     "mi355_last_error": (C.c_char_p, []),
@@ -85,6 +91,8 @@ _SIGNATURES = {
     "mi355_normact_bwd_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mi355_normact_bwd_finalize_into": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp]),
     "mi355_normact_bwd_apply": (C.c_int, [C.POINTER(NormActDesc), _vp]),
+    "mi355_normact_small_fwd": (C.c_int, [C.POINTER(NormSmallDesc), _vp]),
+    "mi355_normact_small_bwd": (C.c_int, [C.POINTER(NormSmallDesc), _vp]),
     "mi355_colsum_finalize": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "mi355_colsum_finalize_into": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp]),
     "mi355_maxpool2_fwd": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

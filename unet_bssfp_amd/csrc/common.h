@@ -72,6 +72,9 @@ template <> struct Vec16<float> {
     const float4 v = *reinterpret_cast<const float4*>(p);
     f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
   }
+  __device__ __forceinline__ void from_bits(const uint4 v) {      // 16 bytes loaded earlier (kept packed while in flight)
+    f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+  }
   __device__ __forceinline__ void store(void* p) const {
     *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
   }
@@ -79,8 +82,8 @@ template <> struct Vec16<float> {
 template <> struct Vec16<bf16_t> {
   static constexpr int N = 8;
   float f[8];
-  __device__ __forceinline__ void load(const void* p) {
-    const uint4 v = *reinterpret_cast<const uint4*>(p);
+  __device__ __forceinline__ void load(const void* p) { from_bits(*reinterpret_cast<const uint4*>(p)); }
+  __device__ __forceinline__ void from_bits(const uint4 v) {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

@@ -537,6 +537,242 @@ __global__ __launch_bounds__(256) void normact_bwd_apply_kernel(const NormActArg
   }
 }
 
+// ------------------------------------------------------------------ norm + act of SMALL tensors, one kernel each way
+// The low levels of the U-Net (16^3 x 256, 8^3 x 512 channels) and the last PatchGAN blocks (16^3 x 128 ... 4^3 x 512) hold
+// 64 KB - 2 MB per tensor: statistics-from-the-conv-epilogue + norm_finalize + normact_fwd (forward) and reduce + finalize +
+// apply (backward) are three launches of 4 - 13 us each on data that fits in L2 -- latency, not bandwidth.  Here ONE
+// workgroup owns EPV channels (one 16-byte piece of every row) of ALL rows and groups: mean, then variance about that mean
+// (two-pass: no sum-of-squares cancellation), then the apply pass, re-reading its L2-resident column; the groups are walked
+// in order, so BatchNorm's running statistics and the affine gradients need no cross-workgroup reduction (deterministic).
+struct NormSmallArgs {
+  NormActArgs q;
+  float eps, momentum;
+  float* mean_out; float* rstd_out;                       // forward: [groups][c], saved for the backward pass
+  float* running_mean; float* running_var; long long* batches_tracked; int n_real;
+  float* dgamma; float* dbeta; int accumulate;            // backward: [n_affine]
+};
+
+constexpr int kSmallThreads = 512, kSmallWaves = kSmallThreads / 64;      // (1024 would cap the kernel at 128 registers: it spilled 500)
+// per-thread f32 partial sums (a few rows each) -> block totals, combined in f64 in a fixed order (the three-launch path
+// combines its per-block partials in f64 too: gradient sums with heavy cancellation keep their sign)
+template <int EPV>
+__device__ __forceinline__ void block_sum_vec(const float (&v)[EPV], double (&t)[EPV], double* red /* [kSmallWaves][EPV] */) {
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) {
+    double d = (double)v[j];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) d += __shfl_xor(d, o, 64);
+    t[j] = d;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();                                        // red may still be read from the previous reduction
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) red[wave * EPV + j] = t[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) {
+    double a = 0.0;
+#pragma unroll
+    for (int w = 0; w < kSmallWaves; ++w) a += red[w * EPV + j];
+    t[j] = a;
+  }
+}
+
+template <typename T, bool DROP>
+__global__ __launch_bounds__(kSmallThreads) void normact_small_fwd_kernel(const NormSmallArgs p) {
+  constexpr int EPV = Elem<T>::kPer16B;
+  __shared__ double red[kSmallWaves * EPV];
+  const NormActArgs& q = p.q;
+  const int ch0 = blockIdx.x * EPV;
+  const unsigned long long seed = DROP ? eff_seed(q.seed, q.seed_ptr) : 0ull;
+  float ga[EPV], be[EPV];
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) {
+    const int ch = ch0 + j;
+    ga[j] = q.gamma ? (ch < q.n_affine ? q.gamma[ch] : 0.f) : 1.f;
+    be[j] = (q.beta && ch < q.n_affine) ? q.beta[ch] : 0.f;
+  }
+  if (p.batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) p.batches_tracked[0] += q.groups;
+  const double inv = 1.0 / (double)q.rows_per_group;
+  for (int g = 0; g < q.groups; ++g) {
+    const T* zb = reinterpret_cast<const T*>(q.z) + (long long)g * q.rows_per_group * q.ldz + ch0;
+    float s[EPV], mu[EPV], rs[EPV];
+    double t[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) s[j] = 0.f;
+    // (512 threads x U rows in flight: the column is L2-resident and a pass is one latency -- with 256 threads walking it one
+    //  dependent load per iteration the kernel took 24 us, longer than the three launches it replaces)
+    constexpr int U = 8;
+    for (long long row0 = threadIdx.x; row0 < q.rows_per_group; row0 += kSmallThreads * U) {
+      uint4 raw[U];                                        // (packed while in flight: 4 registers per row, not EPV)
+#pragma unroll
+      for (int u = 0; u < U; ++u) if (row0 + u * kSmallThreads < q.rows_per_group) raw[u] = *reinterpret_cast<const uint4*>(zb + (row0 + u * kSmallThreads) * q.ldz);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (row0 + u * kSmallThreads < q.rows_per_group) {
+          Vec16<T> v; v.from_bits(raw[u]);
+#pragma unroll
+          for (int j = 0; j < EPV; ++j) s[j] += v.f[j];
+        }
+    }
+    block_sum_vec<EPV>(s, t, red);
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) { mu[j] = (float)(t[j] * inv); s[j] = 0.f; }
+    for (long long row0 = threadIdx.x; row0 < q.rows_per_group; row0 += kSmallThreads * U) {
+      uint4 raw[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) if (row0 + u * kSmallThreads < q.rows_per_group) raw[u] = *reinterpret_cast<const uint4*>(zb + (row0 + u * kSmallThreads) * q.ldz);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (row0 + u * kSmallThreads < q.rows_per_group) {
+          Vec16<T> v; v.from_bits(raw[u]);
+#pragma unroll
+          for (int j = 0; j < EPV; ++j) { const float d = v.f[j] - mu[j]; s[j] += d * d; }
+        }
+    }
+    block_sum_vec<EPV>(s, t, red);
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) rs[j] = (float)(1.0 / sqrt(t[j] * inv + (double)p.eps));
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) {
+        const int ch = ch0 + j;
+        p.mean_out[(long long)g * q.c + ch] = mu[j];
+        p.rstd_out[(long long)g * q.c + ch] = rs[j];
+        if (p.running_mean && ch < p.n_real) {
+          const double var = t[j] * inv;
+          const double unb = q.rows_per_group > 1 ? var * (double)q.rows_per_group / (double)(q.rows_per_group - 1) : var;
+          p.running_mean[ch] = (float)((1.0 - p.momentum) * p.running_mean[ch] + p.momentum * (double)mu[j]);
+          p.running_var[ch] = (float)((1.0 - p.momentum) * p.running_var[ch] + p.momentum * unb);
+        }
+      }
+    }
+    float sc[EPV], sh[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) { sc[j] = ga[j] * rs[j]; sh[j] = be[j] - mu[j] * ga[j] * rs[j]; }
+    T* ab = reinterpret_cast<T*>(q.a) + (long long)g * q.rows_per_group * q.lda + ch0;
+    for (long long row0 = threadIdx.x; row0 < q.rows_per_group; row0 += kSmallThreads * U) {
+      uint4 raw[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) if (row0 + u * kSmallThreads < q.rows_per_group) raw[u] = *reinterpret_cast<const uint4*>(zb + (row0 + u * kSmallThreads) * q.ldz);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long row = row0 + u * kSmallThreads;
+        if (row >= q.rows_per_group) continue;
+        Vec16<T> v; v.from_bits(raw[u]);
+        unsigned keep = 0;
+        if constexpr (DROP) keep = drop_keep_mask<EPV>(seed, ((unsigned long long)g * q.rows_per_group + row) * q.c + ch0, q.thr16);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+          float t2 = v.f[j] * sc[j] + sh[j];
+          if constexpr (DROP) t2 = (keep >> j) & 1u ? t2 * q.drop_scale : 0.f;
+          v.f[j] = t2 > 0.f ? t2 : t2 * q.slope;
+        }
+        if (q.s2d_a.d) {
+          long long srow; int blk, border;
+          s2d_cell(q.s2d_a, (long long)g * q.rows_per_group + row, srow, blk, border);
+          v.store(reinterpret_cast<T*>(q.a) + srow * q.lda + (long long)blk * q.s2d_a.cblk + ch0);
+          s2d_zero_siblings<T>(reinterpret_cast<T*>(q.a), q.s2d_a, srow, blk, border, q.lda, ch0);
+        } else v.store(ab + row * q.lda);
+      }
+    }
+  }
+}
+
+template <typename T, bool DROP>
+__global__ __launch_bounds__(kSmallThreads) void normact_small_bwd_kernel(const NormSmallArgs p) {
+  constexpr int EPV = Elem<T>::kPer16B;
+  __shared__ double red[kSmallWaves * EPV];
+  const NormActArgs& q = p.q;
+  const int ch0 = blockIdx.x * EPV;
+  const unsigned long long seed = DROP ? eff_seed(q.seed, q.seed_ptr) : 0ull;
+  const double inv = 1.0 / (double)q.rows_per_group;
+  double tg[EPV], tb[EPV];
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) { tg[j] = 0.0; tb[j] = 0.0; }
+  for (int g = 0; g < q.groups; ++g) {
+    BwdConst<EPV> k;
+    load_bwd_const<EPV>(q, g, ch0, k);
+    const T* zb = reinterpret_cast<const T*>(q.z) + (long long)g * q.rows_per_group * q.ldz + ch0;
+    const T* db = reinterpret_cast<const T*>(q.da) + (long long)g * q.rows_per_group * q.ldda + ch0;
+    auto load_da = [&](long long row) {
+      if (q.s2d_da.d) return *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(q.da) + s2d_offset(q.s2d_da, (long long)g * q.rows_per_group + row, q.ldda) + ch0);
+      return *reinterpret_cast<const uint4*>(db + row * q.ldda);
+    };
+    float s0[EPV], s1[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+    constexpr int U = 2;                                   // (z and da rows in flight per thread: see the forward kernel)
+    for (long long row0 = threadIdx.x; row0 < q.rows_per_group; row0 += kSmallThreads * U) {
+      uint4 zr[U], dr[U];                                  // (packed while in flight)
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (row0 + u * kSmallThreads < q.rows_per_group) { zr[u] = *reinterpret_cast<const uint4*>(zb + (row0 + u * kSmallThreads) * q.ldz); dr[u] = load_da(row0 + u * kSmallThreads); }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long row = row0 + u * kSmallThreads;
+        if (row >= q.rows_per_group) continue;
+        Vec16<T> zv, dv; zv.from_bits(zr[u]); dv.from_bits(dr[u]);
+        unsigned keep = 0;
+        if constexpr (DROP) keep = drop_keep_mask<EPV>(seed, ((unsigned long long)g * q.rows_per_group + row) * q.c + ch0, q.thr16);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+          float gv, xh;
+          bwd_elem<DROP>(q, (keep >> j) & 1u, k.mu[j], k.rs[j], k.ga[j], k.be[j], zv.f[j], dv.f[j], gv, xh);
+          s0[j] += gv;
+          s1[j] += gv * xh;
+        }
+      }
+    }
+    double t0[EPV], t1[EPV];
+    block_sum_vec<EPV>(s0, t0, red);
+    block_sum_vec<EPV>(s1, t1, red);
+    float kk[EPV], m0[EPV], m1[EPV];
+    const bool sub = q.mean && q.batch_stats;
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+      tb[j] += t0[j]; tg[j] += t1[j];
+      kk[j] = k.ga[j] * k.rs[j];
+      m0[j] = sub ? (float)(t0[j] * inv) : 0.f;
+      m1[j] = sub ? (float)(t1[j] * inv) : 0.f;
+    }
+    T* ob = reinterpret_cast<T*>(q.dz) + (long long)g * q.rows_per_group * q.lddz + ch0;
+    for (long long row0 = threadIdx.x; row0 < q.rows_per_group; row0 += kSmallThreads * U) {
+      uint4 zr[U], dr[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (row0 + u * kSmallThreads < q.rows_per_group) { zr[u] = *reinterpret_cast<const uint4*>(zb + (row0 + u * kSmallThreads) * q.ldz); dr[u] = load_da(row0 + u * kSmallThreads); }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long row = row0 + u * kSmallThreads;
+        if (row >= q.rows_per_group) continue;
+        Vec16<T> zv, dv; zv.from_bits(zr[u]); dv.from_bits(dr[u]);
+        unsigned keep = 0;
+        if constexpr (DROP) keep = drop_keep_mask<EPV>(seed, ((unsigned long long)g * q.rows_per_group + row) * q.c + ch0, q.thr16);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+          float gv, xh;
+          bwd_elem<DROP>(q, (keep >> j) & 1u, k.mu[j], k.rs[j], k.ga[j], k.be[j], zv.f[j], dv.f[j], gv, xh);
+          zv.f[j] = kk[j] * (gv - m0[j] - xh * m1[j]);
+        }
+        zv.store(ob + row * q.lddz);
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+      const int ch = ch0 + j;
+      if (ch < q.n_affine) {
+        if (p.dgamma) p.dgamma[ch] = p.accumulate ? p.dgamma[ch] + (float)tg[j] : (float)tg[j];
+        if (p.dbeta) p.dbeta[ch] = p.accumulate ? p.dbeta[ch] + (float)tb[j] : (float)tb[j];
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ max-pool 2x2x2
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y,
@@ -1178,6 +1414,50 @@ int mi355_normact_bwd_apply(const mi355_normact_desc* d, void* stream) {
     else normact_bwd_apply_kernel<bf16_t, false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
   }
   return mi355_check_launch("normact_bwd_apply");
+}
+
+int mi355_normact_small_fwd(const mi355_normact_small_desc* d, void* stream) {
+  NormSmallArgs p;
+  MI355_REQUIRE(d, "normact_small_fwd: null pointer");
+  int rc = fill_normact(&d->base, &p.q, "normact_small_fwd");
+  if (rc) return rc;
+  MI355_REQUIRE(d->base.a && d->base.lda >= d->base.c && d->mean_out && d->rstd_out, "normact_small_fwd: bad output");
+  MI355_REQUIRE(!d->running_mean || d->running_var, "normact_small_fwd: running_mean without running_var");
+  p.eps = d->eps; p.momentum = d->momentum; p.mean_out = d->mean_out; p.rstd_out = d->rstd_out;
+  p.running_mean = d->running_mean; p.running_var = d->running_var; p.batches_tracked = (long long*)d->batches_tracked;
+  p.n_real = d->n_real > 0 ? d->n_real : d->base.c;
+  p.dgamma = p.dbeta = nullptr; p.accumulate = 0;
+  const int epv = d->base.dtype == MI355_DT_F32 ? 4 : 8;
+  dim3 grid(d->base.c / epv);
+  if (d->base.dtype == MI355_DT_F32) {
+    if (p.q.thr16) normact_small_fwd_kernel<float, true><<<grid, dim3(kSmallThreads), 0, (hipStream_t)stream>>>(p);
+    else normact_small_fwd_kernel<float, false><<<grid, dim3(kSmallThreads), 0, (hipStream_t)stream>>>(p);
+  } else {
+    if (p.q.thr16) normact_small_fwd_kernel<bf16_t, true><<<grid, dim3(kSmallThreads), 0, (hipStream_t)stream>>>(p);
+    else normact_small_fwd_kernel<bf16_t, false><<<grid, dim3(kSmallThreads), 0, (hipStream_t)stream>>>(p);
+  }
+  return mi355_check_launch("normact_small_fwd");
+}
+
+int mi355_normact_small_bwd(const mi355_normact_small_desc* d, void* stream) {
+  NormSmallArgs p;
+  MI355_REQUIRE(d, "normact_small_bwd: null pointer");
+  int rc = fill_normact(&d->base, &p.q, "normact_small_bwd");
+  if (rc) return rc;
+  MI355_REQUIRE(d->base.da && d->base.dz && d->base.mean, "normact_small_bwd: null pointer");
+  p.eps = d->eps; p.momentum = 0.f; p.mean_out = p.rstd_out = nullptr;
+  p.running_mean = p.running_var = nullptr; p.batches_tracked = nullptr; p.n_real = 0;
+  p.dgamma = d->dgamma; p.dbeta = d->dbeta; p.accumulate = d->accumulate;
+  const int epv = d->base.dtype == MI355_DT_F32 ? 4 : 8;
+  dim3 grid(d->base.c / epv);
+  if (d->base.dtype == MI355_DT_F32) {
+    if (p.q.thr16) normact_small_bwd_kernel<float, true><<<grid, dim3(kSmallThreads), 0, (hipStream_t)stream>>>(p);
+    else normact_small_bwd_kernel<float, false><<<grid, dim3(kSmallThreads), 0, (hipStream_t)stream>>>(p);
+  } else {
+    if (p.q.thr16) normact_small_bwd_kernel<bf16_t, true><<<grid, dim3(kSmallThreads), 0, (hipStream_t)stream>>>(p);
+    else normact_small_bwd_kernel<bf16_t, false><<<grid, dim3(kSmallThreads), 0, (hipStream_t)stream>>>(p);
+  }
+  return mi355_check_launch("normact_small_bwd");
 }
 
 int mi355_maxpool2_fwd(const void* x, int32_t ldx, void* y, int32_t ldy, int32_t n, int32_t c, int32_t d, int32_t h,

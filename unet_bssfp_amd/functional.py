@@ -542,13 +542,35 @@ class NormActFn(Function):
 
     @staticmethod
     def forward(ctx, z, part, gamma, beta, conv_bias, cfg: NormCfg, training, running_mean, running_var,
-                s2d_out: bool = False, batches_tracked=None):
+                s2d_out: bool = False, batches_tracked=None, small: bool = False):
         z = ops.as_act(z)
         n, d, h, w, c = z.shape
         rows = n * d * h * w
         groups = n if cfg.kind == "instance" else 1
         mean = rstd = None
         batch_stats = False
+        ctx.small = False
+        if small and cfg.kind != "none" and (cfg.kind == "instance" or training or running_mean is None):
+            # small tensor (low U-Net levels, last PatchGAN blocks): statistics, norm, dropout and activation in ONE launch
+            if rows // groups <= 1:
+                raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(z.shape)}")
+            gp = gamma.detach() if gamma is not None else None
+            bp = beta.detach() if beta is not None else None
+            p = cfg.p if training else 0.0
+            seed = DropoutState.next_salt() if p > 0.0 else 0
+            seed_t = DropoutState.base(z.device) if p > 0.0 else None
+            upd = cfg.kind == "batch" and training and running_mean is not None
+            out = _new_s2d(ops.s2d_shape(n, d, h, w, c), z.dtype, z.device) if s2d_out else None
+            a, mean, rstd = ops.normact_small_fwd(z, groups, gp, bp, cfg.eps, cfg.slope, p, seed, seed_t,
+                                                  running_mean if upd else None, running_var if upd else None, cfg.momentum,
+                                                  batches_tracked if upd else None, out=out, s2d=s2d_out)
+            ctx.small = True
+            ctx.s2d_out = s2d_out
+            ctx.seed_t = seed_t
+            ctx.affine_params = (gamma, beta)
+            ctx.save_for_backward(z, mean, rstd, gp, bp)
+            ctx.meta = (groups, cfg.slope, p, seed, True, gamma.numel() if gamma is not None else 0)
+            return a
         if cfg.kind != "none":
             use_batch = cfg.kind == "instance" or training or running_mean is None
             if use_batch:
@@ -597,6 +619,20 @@ class NormActFn(Function):
         want_affine = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
         gamma_p, beta_p = ctx.affine_params
         sink = sink_of(gamma_p) if (ctx.needs_input_grad[2] and ctx.needs_input_grad[3] and mean is not None) else None
+        if ctx.small:
+            none11 = (None,) * 11
+            if sink is not None and sink_of(beta_p) is sink:
+                dz, _, _ = ops.normact_small_bwd(z, da, groups, mean, rstd, gp, bp, slope, p, seed, batch_stats, s2d=ctx.s2d_out,
+                                                 seed_t=ctx.seed_t, affine_into=(sink_grad(gamma_p), sink_grad(beta_p)),
+                                                 accumulate=not sink.fresh(gamma_p))
+                sink.written(gamma_p)
+                sink.written(beta_p)
+                return (dz,) + none11
+            dz, dgamma, dbeta = ops.normact_small_bwd(z, da, groups, mean, rstd, gp, bp, slope, p, seed, batch_stats,
+                                                      s2d=ctx.s2d_out, seed_t=ctx.seed_t, want_affine=want_affine)
+            dg = dgamma[:nch].contiguous() if (dgamma is not None and ctx.needs_input_grad[2]) else None
+            dbt = dbeta[:nch].contiguous() if (dbeta is not None and ctx.needs_input_grad[3]) else None
+            return (dz, None, dg, dbt) + (None,) * 8
         if sink is not None and sink_of(beta_p) is sink:
             # both affine gradients straight into the parameters' .grad storage (gradsink.py)
             dz, _, _ = ops.normact_bwd(z, da, groups, mean, rstd, gp, bp, slope, p, seed, batch_stats, True,
@@ -604,12 +640,12 @@ class NormActFn(Function):
                                        accumulate=not sink.fresh(gamma_p))
             sink.written(gamma_p)
             sink.written(beta_p)
-            return dz, None, None, None, None, None, None, None, None, None, None
+            return dz, None, None, None, None, None, None, None, None, None, None, None
         dz, dgamma, dbeta = ops.normact_bwd(z, da, groups, mean, rstd, gp, bp, slope, p, seed, batch_stats,
                                             want_affine and mean is not None, s2d=ctx.s2d_out, seed_t=ctx.seed_t)
         dg = dgamma[:nch].contiguous() if (dgamma is not None and ctx.needs_input_grad[2]) else None
         dbt = dbeta[:nch].contiguous() if (dbeta is not None and ctx.needs_input_grad[3]) else None
-        return dz, None, dg, dbt, None, None, None, None, None, None, None
+        return dz, None, dg, dbt, None, None, None, None, None, None, None, None
 
 
 # ====================================================================================== pool / loss

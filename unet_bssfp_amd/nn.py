@@ -191,15 +191,19 @@ class DownSampleConv(_Mi355Module):
         """s2d_cp > 0: x0 is the space-to-depth tensor S(a) with s2d_cp channels per block (k4 s2 p1 only);
         s2d_out: return S(output) for the next k4 s2 p1 block instead of the plain activation."""
         fuse = self.batchnorm and self.training
-        z, part = self.conv.forward_act(x0, x1, want_stats=fuse, zero_bias_grad=fuse, s2d_cp=s2d_cp)
+        n, di, hi, wi = x0.shape[:4]
+        ext = (di - 1, hi - 1, wi - 1) if s2d_cp else tuple(self.conv.spec.out_extent(e) for e in (di, hi, wi))
+        # small outputs (the last PatchGAN blocks): the norm kernel computes the statistics itself, in one launch
+        small = fuse and ops.norm_is_small(n, *ext, round_up(self.conv.out_channels, 16))
+        z, part = self.conv.forward_act(x0, x1, want_stats=fuse and not small, zero_bias_grad=fuse, s2d_cp=s2d_cp)
         if not (self.batchnorm or self.activation):
             assert not s2d_out
             return z
         if self.batchnorm:
             # num_batches_tracked is advanced by the statistics kernel (no launch of its own)
-            return Fn.NormActFn.apply(z, part if fuse else None, self.bn.weight, self.bn.bias, self.conv.bias,
+            return Fn.NormActFn.apply(z, part if (fuse and not small) else None, self.bn.weight, self.bn.bias, self.conv.bias,
                                       self.cfg, self.training, self.bn.running_mean, self.bn.running_var, s2d_out,
-                                      self.bn.num_batches_tracked if self.training else None)
+                                      self.bn.num_batches_tracked if self.training else None, small)
         return Fn.NormActFn.apply(z, None, None, None, None, self.cfg, self.training, None, None, s2d_out)
 
     def forward(self, x):
@@ -265,9 +269,12 @@ class Convolution(_Mi355Module):
         self.cfg = Fn.NormCfg("instance", cout, eps=eps, slope=slope, p=float(dropout or 0.0))
 
     def forward_act(self, x0, x1=None):
-        z, part = self.conv.forward_act(x0, x1, want_stats=True, zero_bias_grad=True)
-        return Fn.NormActFn.apply(z, part, self.adn.N.weight, self.adn.N.bias, self.conv.bias, self.cfg,
-                                  self.training, None, None)
+        n, d, h, w = x0.shape[:4]
+        # small levels (16^3, 8^3): the norm kernel computes the instance statistics itself, in one launch
+        small = ops.norm_is_small(n, d, h, w, round_up(self.conv.out_channels, 16))
+        z, part = self.conv.forward_act(x0, x1, want_stats=not small, zero_bias_grad=True)
+        return Fn.NormActFn.apply(z, part if not small else None, self.adn.N.weight, self.adn.N.bias, self.conv.bias, self.cfg,
+                                  self.training, None, None, False, None, small)
 
 
 class TwoConv(_Mi355Module):

@@ -491,6 +491,74 @@ def normact_bwd(z, da, groups, mean, rstd, gamma, beta, slope, drop_p, seed, bat
     return dz, dgamma, dbeta
 
 
+SMALL_NORM_ELEMENTS = 1 << 20      # tensors of up to 1 M elements (2 MB bf16) with >= 64 channels take the one-launch kernels
+
+
+def norm_is_small(n: int, d: int, h: int, w: int, c: int) -> bool:
+    """Does a (n, d, h, w, c) activation take the fused small-tensor norm kernels (mi355_normact_small_fwd / _bwd)?"""
+    return c >= 64 and n * d * h * w * c <= SMALL_NORM_ELEMENTS
+
+
+def normact_small_fwd(z, groups, gamma, beta, eps, slope, drop_p=0.0, seed=0, seed_t=None, running_mean=None,
+                      running_var=None, momentum=0.0, batches_tracked=None, out=None, s2d=False):
+    """Statistics + norm + dropout + LeakyReLU of a small tensor in ONE launch.  Returns (a, mean, rstd); BatchNorm running
+    statistics (given: training mode) are updated in place."""
+    require_cuda(z, gamma, beta, out, running_mean, running_var)
+    n, dd, h, w, c = z.shape
+    if out is None:
+        out = torch.empty(z.shape, dtype=z.dtype, device=z.device)
+    mean = torch.empty((groups, c), dtype=torch.float32, device=z.device)
+    rstd = torch.empty_like(mean)
+    d = _lib.NormSmallDesc()
+    d.base = _normact_desc(z, groups, None, None, gamma, beta, slope, drop_p, seed, seed_t)
+    d.base.a, d.base.lda = out.data_ptr(), act_ld(out)
+    if s2d:
+        d.base.s2d_a = 1
+        d.base.sd, d.base.sh, d.base.sw = z.shape[1:4]
+    d.eps, d.momentum = eps, momentum
+    d.mean_out, d.rstd_out = mean.data_ptr(), rstd.data_ptr()
+    d.running_mean, d.running_var, d.batches_tracked = _ptr(running_mean), _ptr(running_var), _ptr(batches_tracked)
+    d.n_real = running_mean.numel() if running_mean is not None else 0
+    after = _norm_probe("fwd", z, gamma)
+    _lib.check(_lib.load().mi355_normact_small_fwd(C.byref(d), _stream()), "normact_small_fwd")
+    if after is not None:
+        after()
+    return out, mean, rstd
+
+
+def normact_small_bwd(z, da, groups, mean, rstd, gamma, beta, slope, drop_p, seed, batch_stats, s2d=False, seed_t=None,
+                      affine_into=None, accumulate=False, want_affine=True):
+    """Backward of the above in ONE launch: returns (dz, dgamma, dbeta) -- the affine gradients are None when written into
+    ``affine_into`` (caller-owned f32 vectors of the real channel count) or not wanted."""
+    require_cuda(z, da, mean, rstd)
+    n, dd, h, w, c = z.shape
+    d = _lib.NormSmallDesc()
+    d.base = _normact_desc(z, groups, mean, rstd, gamma, beta, slope, drop_p, seed, seed_t)
+    d.base.da, d.base.ldda = da.data_ptr(), act_ld(da)
+    dz = torch.empty(z.shape, dtype=z.dtype, device=z.device)
+    d.base.dz, d.base.lddz = dz.data_ptr(), act_ld(dz)
+    d.base.batch_stats = 1 if batch_stats else 0
+    if s2d:
+        d.base.s2d_da = 1
+        d.base.sd, d.base.sh, d.base.sw = z.shape[1:4]
+    dgamma = dbeta = None
+    if affine_into is not None:
+        g_into, b_into = affine_into
+        require_cuda(g_into, b_into)
+        assert g_into.dtype == b_into.dtype == torch.float32 and g_into.numel() == b_into.numel() <= c
+        d.base.n_affine = g_into.numel()
+        d.dgamma, d.dbeta, d.accumulate = g_into.data_ptr(), b_into.data_ptr(), 1 if accumulate else 0
+    elif want_affine:
+        dgamma = torch.zeros((c,), dtype=torch.float32, device=z.device)
+        dbeta = torch.zeros((c,), dtype=torch.float32, device=z.device)
+        d.dgamma, d.dbeta, d.accumulate = dgamma.data_ptr(), dbeta.data_ptr(), 0
+    after = _norm_probe("bwd", z, gamma)
+    _lib.check(_lib.load().mi355_normact_small_bwd(C.byref(d), _stream()), "normact_small_bwd")
+    if after is not None:
+        after()
+    return dz, dgamma, dbeta
+
+
 # ------------------------------------------------------------------------------ pooling
 def maxpool2_fwd(x: torch.Tensor) -> torch.Tensor:
     require_cuda(x)
