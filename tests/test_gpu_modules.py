@@ -567,6 +567,63 @@ def test_hipgraph_two_input_sets_equal_eager_steps_on_alternating_batches(hip):
         assert torch.equal(p, q), n
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_discriminator_forward_pair_equals_two_calls(hip, dtype):
+    """Discriminator.forward_pair(x, y_a, y_b) -- the discriminator phase's two calls (src/model.py:184-186) as one pass over
+    the stacked inputs -- against the two separate calls: logits, BatchNorm running statistics and counters after the pair
+    (each half normalised with its own batch statistics, running statistics updated in call order), and the parameter
+    gradients of (BCE(fake, 0) + BCE(real, 1)) / 2.  Same kernels per sample; only summation orders differ."""
+    import copy
+    import unet_bssfp_amd as M
+    torch.manual_seed(3)
+    d0 = M.Discriminator("bssfp")
+    state = copy.deepcopy(d0.state_dict())
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 24, 64, 64, 64, generator=g).to(DEV)
+    ya = torch.rand(2, 6, 64, 64, 64, generator=g).to(DEV)
+    yb = torch.rand(2, 6, 64, 64, 64, generator=g).to(DEV)
+    res = {}
+    for mode in ("pair", "two"):
+        d = M.Discriminator("bssfp")
+        d.load_state_dict(state)
+        d = M.set_compute_dtype(d.to(DEV).train(), dtype)
+        if mode == "pair":
+            la, lb = d.forward_pair(x, ya, yb)
+        else:
+            la, lb = d(x, ya), d(x, yb)
+        bce = torch.nn.functional.binary_cross_entropy_with_logits
+        loss = (bce(la, torch.zeros_like(la)) + bce(lb, torch.ones_like(lb))) / 2
+        loss.backward()
+        torch.cuda.synchronize()
+        res[mode] = (la.detach().float().cpu(), lb.detach().float().cpu(),
+                     {n: p.grad.detach().cpu() for n, p in d.named_parameters() if p.grad is not None},
+                     {n: b.detach().clone().cpu() for n, b in d.named_buffers()})
+    tol = dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-3)
+    torch.testing.assert_close(res["pair"][0], res["two"][0], **tol)
+    torch.testing.assert_close(res["pair"][1], res["two"][1], **tol)
+    assert set(res["pair"][2]) == set(res["two"][2])
+    # gradients: the PatchGAN's BatchNorms see 8 - 16 values per channel at this size, which amplifies every rounding
+    # difference (two f32 evaluations in different summation orders differ by ~1e-3 of the largest element; bf16 storage
+    # moves these gradients by 20 - 45 % rel-L2 against f32, DESIGN.md section 5): direction and size must agree
+    for n, gp in res["pair"][2].items():
+        gt = res["two"][2][n]
+        if float(gt.abs().max()) == 0.0:                      # conv bias in front of a BatchNorm: exact zeros on both sides
+            assert float(gp.abs().max()) == 0.0, n
+            continue
+        rel = float((gp - gt).norm() / gt.norm().clamp_min(1e-30))
+        cos = float(torch.nn.functional.cosine_similarity(gp.flatten().double(), gt.flatten().double(), dim=0))
+        if dtype == torch.float32:
+            assert rel <= 5e-3 and cos >= 0.9999, (n, rel, cos)
+        else:
+            assert rel <= 0.3 and cos >= 0.95, (n, rel, cos)
+    for n, bp in res["pair"][3].items():
+        bt = res["two"][3][n]
+        if bp.dtype == torch.long:
+            assert int(bp) == int(bt) == 2, n                  # two forward calls were counted
+        else:
+            torch.testing.assert_close(bp, bt, **(dict(rtol=1e-3, atol=5e-6) if dtype == torch.float32 else dict(rtol=2e-2, atol=1e-4)))
+
+
 def test_gradient_sinks_equal_autograd_accumulation(hip):
     """gradsink.GradBuckets (gradient kernels write parameter gradients in place, second uses accumulate in the kernel) must
     give the same gradients and the same parameters after two steps as plain autograd accumulation (.grad tensors created by

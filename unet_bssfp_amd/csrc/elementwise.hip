@@ -298,24 +298,29 @@ __global__ __launch_bounds__(1024) void norm_finalize_kernel(const float* __rest
                                                              int n_real, float eps, float* __restrict__ mean,
                                                              float* __restrict__ rstd, float* running_mean,
                                                              float* running_var, float momentum,
-                                                             long long* batches_tracked) {
-  const int g = blockIdx.y;
+                                                             long long* batches_tracked, int groups_here) {
+  // groups_here == 1: this workgroup's group is blockIdx.y.  groups_here > 1 (BatchNorm over several statistic groups in
+  // one call -- the discriminator's fake and real batch stacked, src/model.py:185-186): the groups are walked IN ORDER by one
+  // workgroup per channel block, so that the running statistics receive the momentum updates of two consecutive forward calls.
   const int ch0 = blockIdx.x * 8;
-  if (batches_tracked && blockIdx.x == 0 && g == 0 && threadIdx.x == 0) batches_tracked[0] += 1;   // BatchNorm's counter
-  double s1, s2;
-  block_sum_parts(part + (long long)g * ppg * 2 * c, ppg, c, ch0, s1, s2);
-  const int ch = ch0 + (int)threadIdx.x;
-  if (threadIdx.x >= 8 || ch >= c) return;
-  const double m = s1 / (double)count;
-  double var = s2 / (double)count - m * m;
-  if (var < 0.0) var = 0.0;
-  const double mu = m + ((shift && ch < n_real) ? (double)shift[ch] : 0.0);
-  mean[(long long)g * c + ch] = (float)mu;
-  rstd[(long long)g * c + ch] = (float)(1.0 / sqrt(var + (double)eps));
-  if (running_mean && ch < n_real) {
-    const double unb = count > 1 ? var * (double)count / (double)(count - 1) : var;
-    running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mu);
-    running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
+  if (batches_tracked && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) batches_tracked[0] += groups_here;   // BatchNorm's counter
+  for (int gi = 0; gi < groups_here; ++gi) {
+    const int g = groups_here > 1 ? gi : blockIdx.y;
+    double s1, s2;
+    block_sum_parts(part + (long long)g * ppg * 2 * c, ppg, c, ch0, s1, s2);
+    const int ch = ch0 + (int)threadIdx.x;
+    if (threadIdx.x >= 8 || ch >= c) continue;
+    const double m = s1 / (double)count;
+    double var = s2 / (double)count - m * m;
+    if (var < 0.0) var = 0.0;
+    const double mu = m + ((shift && ch < n_real) ? (double)shift[ch] : 0.0);
+    mean[(long long)g * c + ch] = (float)mu;
+    rstd[(long long)g * c + ch] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean && ch < n_real) {
+      const double unb = count > 1 ? var * (double)count / (double)(count - 1) : var;
+      running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mu);
+      running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
+    }
   }
 }
 
@@ -1294,10 +1299,11 @@ int mi355_norm_finalize(const float* part, int32_t parts_per_group, int32_t grou
                         const float* shift, int32_t n_real, float eps, float* mean, float* rstd, float* running_mean,
                         float* running_var, float momentum, int64_t* batches_tracked, void* stream) {
   MI355_REQUIRE(part && mean && rstd && parts_per_group > 0 && groups > 0 && c > 0 && count_per_group > 0, "norm_finalize: bad argument");
-  MI355_REQUIRE(!running_mean || (running_var && groups == 1), "norm_finalize: running stats need groups == 1");
-  hipLaunchKernelGGL(norm_finalize_kernel, dim3((c + 7) / 8, groups), dim3(1024), 0, (hipStream_t)stream, part,
+  MI355_REQUIRE(!running_mean || running_var, "norm_finalize: running_mean without running_var");
+  const bool serial = running_mean && groups > 1;         // running statistics: the groups' momentum updates in order
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3((c + 7) / 8, serial ? 1 : groups), dim3(1024), 0, (hipStream_t)stream, part,
                      parts_per_group, c, (long long)count_per_group, shift, n_real > 0 ? n_real : c, eps, mean, rstd, running_mean, running_var, momentum,
-                     (long long*)batches_tracked);
+                     (long long*)batches_tracked, serial ? groups : 1);
   return mi355_check_launch("norm_finalize");
 }
 

@@ -542,11 +542,15 @@ class NormActFn(Function):
 
     @staticmethod
     def forward(ctx, z, part, gamma, beta, conv_bias, cfg: NormCfg, training, running_mean, running_var,
-                s2d_out: bool = False, batches_tracked=None, small: bool = False):
+                s2d_out: bool = False, batches_tracked=None, small: bool = False, bn_groups: int = 1):
+        """bn_groups > 1: BatchNorm statistics per consecutive sample group (two forward calls of the discriminator stacked
+        along the batch: each group is normalised with its own batch statistics, the running statistics receive the groups'
+        momentum updates in order -- exactly what two separate calls do)."""
         z = ops.as_act(z)
         n, d, h, w, c = z.shape
         rows = n * d * h * w
-        groups = n if cfg.kind == "instance" else 1
+        groups = n if cfg.kind == "instance" else (bn_groups if cfg.kind == "batch" else 1)
+        assert n % groups == 0
         mean = rstd = None
         batch_stats = False
         ctx.small = False
@@ -620,7 +624,7 @@ class NormActFn(Function):
         gamma_p, beta_p = ctx.affine_params
         sink = sink_of(gamma_p) if (ctx.needs_input_grad[2] and ctx.needs_input_grad[3] and mean is not None) else None
         if ctx.small:
-            none11 = (None,) * 11
+            none11 = (None,) * 12
             if sink is not None and sink_of(beta_p) is sink:
                 dz, _, _ = ops.normact_small_bwd(z, da, groups, mean, rstd, gp, bp, slope, p, seed, batch_stats, s2d=ctx.s2d_out,
                                                  seed_t=ctx.seed_t, affine_into=(sink_grad(gamma_p), sink_grad(beta_p)),
@@ -632,7 +636,7 @@ class NormActFn(Function):
                                                       s2d=ctx.s2d_out, seed_t=ctx.seed_t, want_affine=want_affine)
             dg = dgamma[:nch].contiguous() if (dgamma is not None and ctx.needs_input_grad[2]) else None
             dbt = dbeta[:nch].contiguous() if (dbeta is not None and ctx.needs_input_grad[3]) else None
-            return (dz, None, dg, dbt) + (None,) * 8
+            return (dz, None, dg, dbt) + (None,) * 9
         if sink is not None and sink_of(beta_p) is sink:
             # both affine gradients straight into the parameters' .grad storage (gradsink.py)
             dz, _, _ = ops.normact_bwd(z, da, groups, mean, rstd, gp, bp, slope, p, seed, batch_stats, True,
@@ -640,12 +644,12 @@ class NormActFn(Function):
                                        accumulate=not sink.fresh(gamma_p))
             sink.written(gamma_p)
             sink.written(beta_p)
-            return dz, None, None, None, None, None, None, None, None, None, None, None
+            return dz, None, None, None, None, None, None, None, None, None, None, None, None
         dz, dgamma, dbeta = ops.normact_bwd(z, da, groups, mean, rstd, gp, bp, slope, p, seed, batch_stats,
                                             want_affine and mean is not None, s2d=ctx.s2d_out, seed_t=ctx.seed_t)
         dg = dgamma[:nch].contiguous() if (dgamma is not None and ctx.needs_input_grad[2]) else None
         dbt = dbeta[:nch].contiguous() if (dbeta is not None and ctx.needs_input_grad[3]) else None
-        return dz, None, dg, dbt, None, None, None, None, None, None, None, None
+        return dz, None, dg, dbt, None, None, None, None, None, None, None, None, None
 
 
 # ====================================================================================== pool / loss

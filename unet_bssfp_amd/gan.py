@@ -120,10 +120,18 @@ class bSSFPToDWITensorModel(nn.Module):
         logs[f"{step_name}_gen_loss_adversarial"] = adv.detach()
         return adv + recon, y_hat
 
+    pair_discriminator_calls = True     # HIP discriminator: its two calls of the discriminator phase as one stacked pass
+
+    def _discr_pair(self) -> bool:
+        return self.pair_discriminator_calls and hasattr(self.discr, "forward_pair") and next(self.discr.parameters()).is_cuda
+
     def _discr_step(self, x, y):
         y_hat = self.gen(x).detach()
-        logits_hat = self.discr(x, y_hat)
-        logits = self.discr(x, y)
+        if self._discr_pair():
+            logits_hat, logits = self.discr.forward_pair(x, y_hat, y)
+        else:
+            logits_hat = self.discr(x, y_hat)
+            logits = self.discr(x, y)
         loss_hat = F.binary_cross_entropy_with_logits(logits_hat, torch.zeros_like(logits_hat))
         loss = F.binary_cross_entropy_with_logits(logits, torch.ones_like(logits))
         return (loss + loss_hat) / 2
@@ -238,7 +246,7 @@ class bSSFPToDWITensorModel(nn.Module):
         x, y = self.unpack_batch(batch)
         self._toggle(self.gen, False)
         if self.sinks_discr is not None:
-            self.sinks_discr.begin_phase(2)
+            self.sinks_discr.begin_phase(1 if self._discr_pair() else 2)     # gradient contributions per parameter in this phase
         if staged:
             from .functional import StageBoundary
             self._stage_sinks = self.sinks_discr

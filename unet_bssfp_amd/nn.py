@@ -187,9 +187,10 @@ class DownSampleConv(_Mi355Module):
         self.cfg = Fn.NormCfg("batch" if batchnorm else "none", out_channels, eps=1e-5, momentum=0.1,
                               slope=0.2 if activation else 1.0)
 
-    def forward_act(self, x0, x1=None, s2d_cp=0, s2d_out=False):
+    def forward_act(self, x0, x1=None, s2d_cp=0, s2d_out=False, bn_groups=1):
         """s2d_cp > 0: x0 is the space-to-depth tensor S(a) with s2d_cp channels per block (k4 s2 p1 only);
-        s2d_out: return S(output) for the next k4 s2 p1 block instead of the plain activation."""
+        s2d_out: return S(output) for the next k4 s2 p1 block instead of the plain activation;
+        bn_groups: BatchNorm statistics per consecutive sample group (Discriminator.forward_pair)."""
         fuse = self.batchnorm and self.training
         n, di, hi, wi = x0.shape[:4]
         ext = (di - 1, hi - 1, wi - 1) if s2d_cp else tuple(self.conv.spec.out_extent(e) for e in (di, hi, wi))
@@ -203,7 +204,7 @@ class DownSampleConv(_Mi355Module):
             # num_batches_tracked is advanced by the statistics kernel (no launch of its own)
             return Fn.NormActFn.apply(z, part if (fuse and not small) else None, self.bn.weight, self.bn.bias, self.conv.bias,
                                       self.cfg, self.training, self.bn.running_mean, self.bn.running_var, s2d_out,
-                                      self.bn.num_batches_tracked if self.training else None, small)
+                                      self.bn.num_batches_tracked if self.training else None, small, bn_groups)
         return Fn.NormActFn.apply(z, None, None, None, None, self.cfg, self.training, None, None, s2d_out)
 
     def forward(self, x):
@@ -248,6 +249,34 @@ class Discriminator(_Mi355Module):
                     Fn.StageBoundary.mark(h)
         z, _ = self.final.forward_act(h)
         return Fn.UnpackFn.apply(z, 1)
+
+    def forward_pair(self, x, y_a, y_b):
+        """(self(x, y_a), self(x, y_b)) in ONE pass over the two inputs stacked along the batch -- the discriminator phase
+        calls the network on the fake and on the real batch back to back (src/model.py:184-186).  Every BatchNorm normalises
+        each half with its own batch statistics and updates the running statistics in call order (first y_a, then y_b), so
+        the results are those of the two separate calls; the weight gradients arrive as one sum over both halves.  Half the
+        launches of a phase whose kernels (32^3 x 64 ... 4^3 x 512) cannot fill the chip one call at a time."""
+        ops.require_cuda(x, y_a, y_b)
+        n = x.shape[0]
+        cin = x.shape[1] + y_a.shape[1]
+        cp = round_up(cin, 16)
+        blocks = (self.d1[self.modality], self.d2, self.d3, self.d4, self.d5)
+        s2d = all(e % 32 == 0 for e in x.shape[2:])
+        if not s2d or y_a.requires_grad or y_b.requires_grad or x.requires_grad:
+            return self(x, y_a), self(x, y_b)                       # (general case: two calls)
+        d, hh, w = x.shape[2:]
+        h = Fn._new_s2d(ops.s2d_shape(2 * n, d, hh, w, cp), self.compute_dtype, x.device)
+        x32 = x.detach().to(torch.float32).contiguous()
+        for half, y in enumerate((y_a, y_b)):
+            ops.pack2(x32, y.detach().to(torch.float32).contiguous(), h[half * n:(half + 1) * n], 0, cp, s2d_cblk=cp)
+        for i, blk in enumerate(blocks):
+            h = blk.forward_act(h, s2d_cp=cp, s2d_out=i < 4, bn_groups=2)
+            cp = round_up(blk.conv.out_channels, 16)
+            if i == 1 and blk.conv.weight.requires_grad:
+                Fn.StageBoundary.mark(h)
+        z, _ = self.final.forward_act(h)
+        logits = Fn.UnpackFn.apply(z, 1)
+        return logits[:n], logits[n:]
 
 
 # ------------------------------------------------------------------------------------------
