@@ -621,7 +621,7 @@ def test_discriminator_forward_pair_equals_two_calls(hip, dtype):
         if bp.dtype == torch.long:
             assert int(bp) == int(bt) == 2, n                  # two forward calls were counted
         else:
-            torch.testing.assert_close(bp, bt, **(dict(rtol=1e-3, atol=5e-6) if dtype == torch.float32 else dict(rtol=2e-2, atol=1e-4)))
+            torch.testing.assert_close(bp, bt, **(dict(rtol=1e-3, atol=5e-6) if dtype == torch.float32 else dict(rtol=5e-2, atol=1e-3)))
 
 
 def test_gradient_sinks_equal_autograd_accumulation(hip):
