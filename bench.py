@@ -84,6 +84,7 @@ def parse():
                     help="world size > 1: broadcast rank 0's BatchNorm running statistics before every k-th step "
                          "(DDP's broadcast_buffers=True, src/train.py:30; 0 = never)")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch (--gpus N without torch.distributed.run): rendezvous port (0 = pick a free one)")
+    ap.add_argument("--side-stream", action="store_true", help="developer A/B: weight gradients of the small layers on a second stream (measured slower); reported")
     ap.add_argument("--small-norm-elements", type=int, default=None,
                     help="developer A/B: size limit of the one-launch norm kernels (0 = off); reported")
     ap.add_argument("--lib", default=None, help="developer A/B: another build of the C ABI (tools/diaglib.py); reported")
@@ -407,6 +408,10 @@ def main():
     from unet_bssfp_amd import ddp, ops
     from unet_bssfp_amd.gan import bSSFPToDWITensorModel, synthetic_batch
 
+    if a.side_stream:
+        from unet_bssfp_amd import functional as _Fn
+        _Fn.SideStream.allowed = True
+        nondefault["side_stream"] = True
     if a.small_norm_elements is not None:
         ops.SMALL_NORM_ELEMENTS = a.small_norm_elements
         nondefault["small_norm_elements"] = a.small_norm_elements

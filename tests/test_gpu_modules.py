@@ -624,6 +624,35 @@ def test_discriminator_forward_pair_equals_two_calls(hip, dtype):
             torch.testing.assert_close(bp, bt, **(dict(rtol=1e-3, atol=5e-6) if dtype == torch.float32 else dict(rtol=5e-2, atol=1e-3)))
 
 
+def test_side_stream_weight_gradients_equal_main_stream(hip):
+    """functional.SideStream (weight gradients of the small layers on a second stream; off by default: measured slower) must
+    not change a single bit, eagerly and under hipGraph capture (fork / join edges inside the captured step)."""
+    import unet_bssfp_amd as M
+    from unet_bssfp_amd import functional as Fn
+    from unet_bssfp_amd.functional import DropoutState
+    from unet_bssfp_amd.gan import GraphedTrainingStep, bSSFPToDWITensorModel, synthetic_batch
+    batch = synthetic_batch(2, 32, seed=9, device=DEV)
+    out = {}
+    try:
+        for mode in ("off", "on_eager", "on_graph"):
+            Fn.SideStream.allowed = mode != "off"
+            torch.manual_seed(4)
+            DropoutState.reset()
+            model = bSSFPToDWITensorModel("bssfp", gen=M.Generator("bssfp", dropout=0.05).to(DEV), discr=M.Discriminator("bssfp").to(DEV)).train()
+            if mode == "on_graph":
+                gs = GraphedTrainingStep(model, batch, warmup=2)
+                gs(); gs()
+            else:
+                for i in range(4):
+                    model.training_step(batch, i)
+            torch.cuda.synchronize()
+            out[mode] = [p.detach().clone() for p in model.parameters()]
+    finally:
+        Fn.SideStream.allowed = False
+    for mode in ("on_eager", "on_graph"):
+        assert all(torch.equal(a, b) for a, b in zip(out["off"], out[mode])), mode
+
+
 def test_gradient_sinks_equal_autograd_accumulation(hip):
     """gradsink.GradBuckets (gradient kernels write parameter gradients in place, second uses accumulate in the kernel) must
     give the same gradients and the same parameters after two steps as plain autograd accumulation (.grad tensors created by

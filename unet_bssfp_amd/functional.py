@@ -139,6 +139,56 @@ class StageBoundary:
         return out
 
 
+class SideStream:
+    """Weight gradients of the SMALL layers (32^3 and below: kernels of 5 - 60 us that cannot fill 256 CUs) on a second HIP
+    stream, beside the data-gradient chain they do not feed: a quarter of the step is kernels shorter than 25 us.  MEASURED
+    SLOWER (see ``allowed``) and therefore off by default; kept as a switch because the test suite covers it.  (The same for the full-resolution layers was measured slower in round 1: two
+    chip-filling kernels thrash each other's L2 and LDS.)  Opt-in per backward pass (``scope()``: the harness's
+    ``manual_backward``), joined before the pass returns and before any gradient bucket is exchanged; works under hipGraph
+    capture (fork / join become graph edges).  Tensors the side kernels read are kept alive until the join: the caching
+    allocator would otherwise hand their memory to later kernels of the main stream."""
+    enabled = False
+    max_rows = 40000            # output positions (n d h w) up to which a layer's weight gradient goes to the side stream
+    _stream = None
+    _dirty = False
+    _keep = []
+
+    @classmethod
+    def run(cls, fn, *keep):
+        if cls._stream is None:
+            cls._stream = torch.cuda.Stream()
+        ev = torch.cuda.Event()
+        ev.record()                                     # everything the side kernels read has been enqueued on the main stream
+        cls._stream.wait_event(ev)
+        with torch.cuda.stream(cls._stream):
+            fn()
+        cls._keep.extend(t for t in keep if t is not None)
+        cls._dirty = True
+
+    @classmethod
+    def join(cls):
+        if cls._dirty:
+            ev = torch.cuda.Event()
+            ev.record(cls._stream)
+            torch.cuda.current_stream().wait_event(ev)
+            cls._keep.clear()
+            cls._dirty = False
+
+    class scope:
+        def __enter__(self):
+            self.prev = SideStream.enabled
+            SideStream.enabled = SideStream.allowed
+            return self
+
+        def __exit__(self, *exc):
+            SideStream.join()
+            SideStream.enabled = self.prev
+            return False
+
+    allowed = False             # OFF: measured 12.48 against 12.27 ms per step with it (interleaved A/B, round 3): the fork / join
+                                # edges of ~70 small launches cost more than the overlap returns; bench.py --side-stream turns it on
+
+
 # ====================================================================================== layout
 class PackMemo:
     """Packed form of constant NCDHW inputs, valid within ONE training step (``clear()`` runs at the start of every
@@ -456,6 +506,7 @@ class ConvFn(Function):
                 ops.conv_fwd(dz, None, wp, coutp, None, 2, 2, (0, 0, 0), dxc, (di, hi, wi), real=(spec.cout, spec.cin))
             dx0 = dxc[..., :c0] if c1 else dxc
             dx1 = dxc[..., c0:] if c1 else None
+        side = SideStream.enabled and n * do_ * ho * wo <= SideStream.max_rows
         if ctx.needs_input_grad[2]:
             # gradient storage owned by the path (gradsink.GradBuckets): the kernel writes (or, for a second use of the
             # layer in this backward pass, accumulates) straight into weight.grad and autograd gets None
@@ -463,21 +514,28 @@ class ConvFn(Function):
             wsink = sink_of(weight)
             acc = wsink is not None and not wsink.fresh(weight)
             dwt = sink_grad(weight) if wsink is not None else torch.empty_like(weight, dtype=torch.float32)
-            if ctx.s2d_cp:
-                ops.conv_wgrad(x0, None, dz, (do_, ho, wo), 1, (0, 0, 0), 2, 1, (0, 0, 0), dwt, spec.cout, spec.cin,
-                               spec.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (2, 2, 2), s2d_cp=ctx.s2d_cp, accumulate=acc)
-            elif spec.kind == "conv":
-                ops.conv_wgrad(x0, x1, dz, (do_, ho, wo), 1, (0, 0, 0), k, spec.stride, (spec.pad,) * 3, dwt,
-                               spec.cout, spec.cin, spec.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (1, 1, 1), accumulate=acc)
-            elif dtype == torch.bfloat16 and spec.cout % 32 == 0 and cg == spec.cout:
-                # transposed conv: the 8 classes are 8*Cout GEMM columns of one k=1 weight-gradient launch
-                ops.conv_wgrad(x0, None, dz, (di, hi, wi), 1, (0, 0, 0), 1, 1, (0, 0, 0), dwt,
-                               spec.cout, spec.cin, 8, spec.cout * 8, (4, 2, 1), (0, 0, 0), (0, 0, 0),
-                               g_cls_cout=spec.cout, accumulate=acc)
+
+            def wgrad():
+                if ctx.s2d_cp:
+                    ops.conv_wgrad(x0, None, dz, (do_, ho, wo), 1, (0, 0, 0), 2, 1, (0, 0, 0), dwt, spec.cout, spec.cin,
+                                   spec.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (2, 2, 2), s2d_cp=ctx.s2d_cp, accumulate=acc)
+                elif spec.kind == "conv":
+                    ops.conv_wgrad(x0, x1, dz, (do_, ho, wo), 1, (0, 0, 0), k, spec.stride, (spec.pad,) * 3, dwt,
+                                   spec.cout, spec.cin, spec.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (1, 1, 1), accumulate=acc)
+                elif dtype == torch.bfloat16 and spec.cout % 32 == 0 and cg == spec.cout:
+                    # transposed conv: the 8 classes are 8*Cout GEMM columns of one k=1 weight-gradient launch
+                    ops.conv_wgrad(x0, None, dz, (di, hi, wi), 1, (0, 0, 0), 1, 1, (0, 0, 0), dwt,
+                                   spec.cout, spec.cin, 8, spec.cout * 8, (4, 2, 1), (0, 0, 0), (0, 0, 0),
+                                   g_cls_cout=spec.cout, accumulate=acc)
+                else:
+                    for cls in CLASSES8:
+                        ops.conv_wgrad(x0, None, dz, (di, hi, wi), 2, cls, 1, 1, (0, 0, 0), dwt,
+                                       spec.cout, spec.cin, 8, spec.cout * 8, (4, 2, 1), cls, (0, 0, 0), accumulate=acc)
+
+            if side and wsink is not None:
+                SideStream.run(wgrad, x0, x1, dz)
             else:
-                for cls in CLASSES8:
-                    ops.conv_wgrad(x0, None, dz, (di, hi, wi), 2, cls, 1, 1, (0, 0, 0), dwt,
-                                   spec.cout, spec.cin, 8, spec.cout * 8, (4, 2, 1), cls, (0, 0, 0), accumulate=acc)
+                wgrad()
             if wsink is not None:
                 wsink.written(weight)
             else:
@@ -490,7 +548,11 @@ class ConvFn(Function):
                 else:
                     db = _cached_zeros(spec.cout, dev)
             elif bsink is not None:
-                ops.colsum_into(dz, sink_grad(ctx.bias_param), accumulate=not bsink.fresh(ctx.bias_param))
+                fresh = bsink.fresh(ctx.bias_param)
+                if side:
+                    SideStream.run(lambda: ops.colsum_into(dz, sink_grad(ctx.bias_param), accumulate=not fresh), dz)
+                else:
+                    ops.colsum_into(dz, sink_grad(ctx.bias_param), accumulate=not fresh)
                 bsink.written(ctx.bias_param)
             else:
                 db = ops.colsum(dz)[: spec.cout].contiguous()

@@ -187,15 +187,26 @@ class bSSFPToDWITensorModel(nn.Module):
         """``manual_backward``.  staged: only the late stage (down to the activations marked by Fn.StageBoundary); the
         early stage follows in ``_backward_early`` -- the caller exchanges the late bucket in between."""
         if not staged:
-            loss.backward()
+            with self._side_scope():
+                loss.backward()
             return
         from .functional import StageBoundary
         boundary = StageBoundary.end()
         sinks = self._stage_sinks
         late = [p for p in sinks.params[0] if p.requires_grad]
-        grads = torch.autograd.grad([loss], boundary + late, retain_graph=True, allow_unused=True)
+        with self._side_scope():
+            grads = torch.autograd.grad([loss], boundary + late, retain_graph=True, allow_unused=True)
         assert all(g is None for g in grads[len(boundary):]), "staged backward needs gradient sinks"
         self._stage = (boundary, list(grads[: len(boundary)]), [p for p in sinks.params[1] if p.requires_grad])
+
+    def _side_scope(self):
+        """Weight gradients of the small layers on a side stream for the duration of this backward pass (HIP networks)."""
+        import contextlib
+        import sys
+        fn = sys.modules.get(__package__ + ".functional")
+        if fn is None or self.sinks_gen is None:
+            return contextlib.nullcontext()
+        return fn.SideStream.scope()
 
     @staticmethod
     def _close_stage_boundary():
@@ -209,7 +220,8 @@ class bSSFPToDWITensorModel(nn.Module):
     def _backward_early(self):
         boundary, grads, early = self._stage
         self._stage = None
-        torch.autograd.backward(boundary, grads, inputs=early)
+        with self._side_scope():
+            torch.autograd.backward(boundary, grads, inputs=early)
 
     # The step is split at the points where gradients cross ranks, so that it can run eagerly
     # (training_step) or as hipGraph segments with the collectives in between (GraphedTrainingStep).
@@ -292,7 +304,8 @@ class bSSFPToDWITensorModel(nn.Module):
             if self.enable_grad_sinks():
                 self.sinks_gen.begin_phase(1)
         loss = self._l1(self.gen(x), y)
-        loss.backward()
+        with self._side_scope():
+            loss.backward()
         self._finish_grads("gen")
         gen_opt, _ = self.optimizers()
         gen_opt.step()

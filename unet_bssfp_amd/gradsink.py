@@ -29,6 +29,13 @@ def sink_of(p: Optional[torch.Tensor]):
     return getattr(p, "_mi355_sink", None) if p is not None else None
 
 
+def _join_side_stream():
+    import sys
+    fn = sys.modules.get(__package__ + ".functional")
+    if fn is not None:
+        fn.SideStream.join()
+
+
 def sink_grad(p: torch.Tensor) -> torch.Tensor:
     """``p.grad`` of a parameter owned by a GradBuckets object -- the permanent view into its bucket.  A caller that ran
     ``optimizer.zero_grad()`` (``set_to_none=True`` is torch's default) after the sinks were enabled has dropped that view:
@@ -123,6 +130,7 @@ class GradBuckets:
         afterwards overlap it."""
         if not self.exchange or self._work[b] is not None:
             return
+        _join_side_stream()                          # weight-gradient kernels on the side stream write into this bucket
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         self._work[b] = dist.all_reduce(self.flat[b], op=op, group=self.group, async_op=True)
         self.launch_order.append(b)
