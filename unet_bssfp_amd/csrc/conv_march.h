@@ -39,6 +39,9 @@
 #pragma once
 #include "conv_common.h"
 
+#ifndef MARCH_TICKET_FRONT
+#define MARCH_TICKET_FRONT (NGR * 2 / 3)
+#endif
 constexpr int kMarchFH = 16, kMarchFW = 32, kMarchHR = kMarchFH + 2, kMarchHC = kMarchFW + 2;
 constexpr int kMarchVox = kMarchHR * kMarchHC;                       // 612 halo voxels per plane
 
@@ -312,10 +315,13 @@ __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, co
     int e_next = vtab[0];
 #pragma unroll
     for (int gi = 0; gi < NGR; ++gi) {
-      // copy ticket i goes behind group (i * NGR) / NI
+      // copy ticket i goes behind group (i * FRONT) / NI: spread over the FIRST part of the step only -- the step ends with a
+      // wait for ALL copies (two plane buffers), so the last ticket needs a memory latency of MFMA work behind it
+      constexpr int FRONT = MARCH_TICKET_FRONT;
+      static_assert(FRONT >= NI && FRONT <= NGR, "one ticket per group at most");
       int ticket = -1;
 #pragma unroll
-      for (int i = 0; i < NI; ++i) if ((i * NGR) / NI == gi) ticket = i;
+      for (int i = 0; i < NI; ++i) if ((i * FRONT) / NI == gi) ticket = i;
       const int e_cur = e_next;
       if (ticket >= 0 && ticket + 1 < NI) e_next = vtab[(ticket + 1) * 256];
       if (gi + 1 < NGR) load_group(g[(gi + 1) & 1], pl, 2 - (gi + 1) / NG, (gi + 1) % NG);
