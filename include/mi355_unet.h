@@ -238,6 +238,11 @@ typedef struct mi355_normact_desc {
    * per-call salt): a launch captured in a hipGraph draws a new mask on every replay */
   const uint64_t* seed_ptr;
   int32_t n_affine;               /* length of gamma/beta (0: c); channels beyond it use gamma 0, beta 0 */
+  /* optional e4m3 copy for the fp8 convolution that consumes the result (BASELINE.json configs[4], delayed per-tensor
+   * scaling): fwd writes q8 = e4m3(a * 224 / q_use[0]), bwd_apply q8 = e4m3(dz * 224 / q_use[0]) -- byte for byte what
+   * mi355_cast_fp8 makes of the stored bf16 tensor -- one byte per channel, row stride ld8 bytes, and raises q_next[0] to
+   * max |a| (|dz|), the scale of the NEXT step (mi355_fp8_scale_roll).  bf16, c == 32, plain layouts only.  NULL: off. */
+  void* q8; int32_t ld8; const float* q_use; float* q_next;
 } mi355_normact_desc;
 int mi355_normact_fwd(const mi355_normact_desc* d, void* stream);
 int mi355_normact_bwd_reduce(const mi355_normact_desc* d, void* stream);
@@ -400,6 +405,13 @@ int mi355_amax_f32(const float* x, int64_t n, float* amax, void* stream);
 int mi355_amax_act(const void* x, int32_t ld, int32_t c, int64_t rows, int32_t dtype, float* amax, void* stream);
 int mi355_cast_fp8(const void* src, int32_t ld_src, int32_t c, int64_t rows, int32_t src_dtype, const float* amax,
                    void* dst, int32_t ld_dst, void* stream);
+/* Delayed scaling (the producer of an operand cannot know its amax before it has written it): the cast uses amax[0], the
+ * amax gathered during the PREVIOUS training step, and raises amax_next[0] (may be NULL) to max |src|; values beyond
+ * 2 * amax saturate at +-448.  mi355_fp8_scale_roll: table[n][2] = (amax in use, amax being gathered); once per step
+ * in-use = gathered where gathered > 0, gathered = 0.  The first step of a layer uses mi355_amax_act + mi355_cast_fp8. */
+int mi355_cast_fp8_delayed(const void* src, int32_t ld_src, int32_t c, int64_t rows, int32_t src_dtype, const float* amax,
+                           float* amax_next, void* dst, int32_t ld_dst, void* stream);
+int mi355_fp8_scale_roll(float* table, int32_t n, void* stream);
 int mi355_fp8_selftest(float* out_1024, void* stream);
 
 #ifdef __cplusplus

@@ -176,10 +176,16 @@ def test_fp8_gan_step_at_config5_size_160(hip):
             ops.CONV_PROBE = None
         torch.cuda.synchronize()
         logs[mode] = {k: float(v) for k, v in model.last_logs.items()}
-        params[mode] = [p.detach().clone() for p in model.parameters()]
         if mode == "fp8":
             after = used_parameters(model.gen, "bssfp") + used_parameters(model.discr, "bssfp")
             assert all(not torch.equal(a, b) for a, b in zip(before, after)), "a used parameter did not move"
+        if mode != "bf16":
+            # a second step: the delayed-scaling path (previous step's amax, e4m3 copies written by the norm kernels)
+            model.training_step(batch, 1)
+            torch.cuda.synchronize()
+            logs[mode + "_step1"] = {k: float(v) for k, v in model.last_logs.items()}
+            assert all(np.isfinite(v) for v in logs[mode + "_step1"].values())
+        params[mode] = [p.detach().clone() for p in model.parameters()]
         del model, g, d
         torch.cuda.empty_cache()
     e4m3 = [p for p in plans if p[1] == 3]
@@ -195,6 +201,102 @@ def test_fp8_gan_step_at_config5_size_160(hip):
         got = logs["fp8"][k]
         assert np.isfinite(got)
         assert abs(got - ref) <= (5e-3 if "discr" not in k else 2e-2) * abs(ref), (k, got, ref)
-    assert logs["fp8"] == logs["fp8_again"]
+    assert logs["fp8"] == logs["fp8_again"] and logs["fp8_step1"] == logs["fp8_again_step1"]
+    assert abs(logs["fp8_step1"]["train_gen_loss_recon_L1"] - logs["fp8"]["train_gen_loss_recon_L1"]) < 0.1 * logs["fp8"]["train_gen_loss_recon_L1"]
     assert all(torch.equal(a, b) for a, b in zip(params["fp8"], params["fp8_again"]))
     assert all(torch.isfinite(p).all() for p in params["fp8"])
+
+
+def test_fp8_producer_side_copies_equal_the_cast_of_the_stored_tensor(hip):
+    """Delayed scaling, kernel level: the e4m3 copy that normact_fwd / normact_bwd write next to their bf16 result must be
+    byte for byte what mi355_cast_fp8 makes of that bf16 tensor with the same amax, and the amax they gather must be the
+    one mi355_amax_act finds (bit-exact: max is order-independent); the one-pass cast gathers the same; the roll kernel
+    moves gathered -> in use only where something was gathered."""
+    from unet_bssfp_amd import ops
+    g = torch.Generator().manual_seed(12)
+    n, d, h, w, c = 2, 9, 20, 24, 32
+    z = (torch.randn(n, d, h, w, c, generator=g) * 3).to(torch.bfloat16).to(DEV)
+    da = torch.randn(n, d, h, w, c, generator=g).to(torch.bfloat16).to(DEV)
+    gamma = (torch.rand(c, generator=g) + 0.5).to(DEV)
+    beta = (torch.rand(c, generator=g) - 0.5).to(DEV)
+    part, bpg = ops.channel_stats(z, n)
+    mean, rstd = ops.norm_finalize(part, bpg, n, c, d * h * w, None, 1e-5)
+    for p, seed in ((0.0, 0), (0.1, 77)):
+        table = torch.tensor([[1.7, 0.0], [0.031, 0.0]], dtype=torch.float32, device=DEV)   # amax in use: neither is the true amax
+        a8 = torch.empty((n, d, h, w, c), dtype=torch.uint8, device=DEV)
+        a = ops.normact_fwd(z, n, mean, rstd, gamma, beta, 0.1, p, seed, q8=(a8, table[0, 0:1], table[0, 1:2]))
+        assert torch.equal(a, ops.normact_fwd(z, n, mean, rstd, gamma, beta, 0.1, p, seed))            # the bf16 result is untouched
+        assert torch.equal(a8, ops.cast_fp8(a, table[0, 0:1]))
+        assert float(table[0, 1]) == float(ops.amax_act(a)) > 1.7                                     # (some values saturate)
+        dz8 = torch.empty((n, d, h, w, c), dtype=torch.uint8, device=DEV)
+        dz, dg, db = ops.normact_bwd(z, da, n, mean, rstd, gamma, beta, 0.1, p, seed, True, True, q8=(dz8, table[1, 0:1], table[1, 1:2]))
+        dz_plain, dg2, db2 = ops.normact_bwd(z, da, n, mean, rstd, gamma, beta, 0.1, p, seed, True, True)
+        assert torch.equal(dz, dz_plain) and torch.equal(dg, dg2) and torch.equal(db, db2)
+        assert torch.equal(dz8, ops.cast_fp8(dz, table[1, 0:1]))
+        assert float(table[1, 1]) == float(ops.amax_act(dz))
+        nxt = torch.zeros(1, device=DEV)
+        assert torch.equal(ops.cast_fp8(a, table[0, 0:1], nxt), a8) and float(nxt) == float(table[0, 1])
+        gathered = table[:, 1].clone()
+        table2 = torch.cat([table, torch.tensor([[0.5, 0.0]], device=DEV)])                        # a slot nobody touched
+        ops.fp8_scale_roll(table2, 3)
+        assert torch.equal(table2[:2, 0], gathered) and float(table2[2, 0]) == 0.5 and float(table2[:, 1].abs().max()) == 0.0
+    with pytest.raises(RuntimeError, match="e4m3 copy"):                                              # 64 channels: not offered
+        z64 = torch.zeros(1, 4, 4, 4, 64, dtype=torch.bfloat16, device=DEV)
+        ops.normact_fwd(z64, 1, None, None, None, None, 0.1, q8=(torch.empty(1, 4, 4, 4, 64, dtype=torch.uint8, device=DEV),
+                                                                table[0, 0:1], table[0, 1:2]))
+
+
+def test_fp8_delayed_scaling_steps_producer_side_equals_cast_side_and_graph_replay(hip):
+    """Delayed scaling, step level.  From the second training step on the e4m3 operands are scaled with the previous
+    step's amax; the copies come from the producing norm kernels (forward activations, incoming gradients).  (i) Four
+    training steps with the producer-side copies must equal, bit for bit, four steps in which every operand takes the
+    one-pass cast instead (same bytes, same gathered amax) -- and the producer side really ran: fewer cast launches;
+    (ii) the step captured in a hipGraph (scale roll, copies and gathering on the device) replays to the same parameters;
+    (iii) every slot the step used is primed and holds a scale."""
+    import unet_bssfp_amd as M
+    from unet_bssfp_amd import functional as Fn, ops
+    from unet_bssfp_amd.functional import DropoutState, Fp8Scales
+    from unet_bssfp_amd.gan import GraphedTrainingStep, bSSFPToDWITensorModel, synthetic_batch
+
+    def build():
+        torch.manual_seed(6)
+        DropoutState.reset()
+        gen, discr = M.Generator("bssfp", dropout=0.05), M.Discriminator("bssfp")
+        model = bSSFPToDWITensorModel("bssfp", gen=gen.to(DEV), discr=discr.to(DEV)).train()
+        return M.set_compute_dtype(model, "fp8")
+
+    batch = synthetic_batch(1, 64, seed=21, device=DEV)
+    casts = {}
+    real_cast = ops.cast_fp8
+    results = {}
+    try:
+        for mode in ("producer", "cast"):
+            Fp8Scales.producer_side = mode == "producer"
+            count = [0]
+
+            def counting(*a, **k):
+                count[0] += 1
+                return real_cast(*a, **k)
+            ops.cast_fp8 = counting
+            model = build()
+            for i in range(4):
+                model.training_step(batch, i)
+            torch.cuda.synchronize()
+            casts[mode] = count[0]
+            results[mode] = [p.detach().clone() for p in model.parameters()]
+            slots = [s for m in model.modules() if hasattr(m, "spec") for s in getattr(m.spec, "_fp8_slots", {}).values()]
+            assert slots and all(s.primed or s.touched for s in slots)
+            assert all(float(s.use) > 0 for s in slots)
+    finally:
+        ops.cast_fp8 = real_cast
+        Fp8Scales.producer_side = True
+    assert casts["producer"] < casts["cast"], casts
+    for p, q in zip(results["producer"], results["cast"]):
+        assert torch.equal(p, q)
+    graphed = build()
+    gs = GraphedTrainingStep(graphed, batch, warmup=2)
+    gs()
+    gs()
+    torch.cuda.synchronize()
+    for (name, q), p in zip(graphed.named_parameters(), results["producer"]):
+        assert torch.equal(p, q), name

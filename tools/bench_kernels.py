@@ -105,6 +105,16 @@ def bench_norm(dtype, reps, only=None):
         print(f"normact fwd (p=.05) {name:16s} {ms*1e3:9.1f} us  {2*nb/ms/1e6:8.1f} GB/s (2 passes)")
         ms = timeit(lambda: ops.normact_fwd(z, 1, mean, rstd, gamma, beta, 0.1, 0.0, 0, out=out), reps)
         print(f"normact fwd (p=0)   {name:16s} {ms*1e3:9.1f} us  {2*nb/ms/1e6:8.1f} GB/s (2 passes)")
+        if c == 32 and dtype == torch.bfloat16:
+            tab = torch.tensor([[3.0, 0.0]], device=DEV)
+            a8 = torch.empty(z.shape, dtype=torch.uint8, device=DEV)
+            for p_, sd in ((0.05, 1234), (0.0, 0)):
+                ms = timeit(lambda: ops.normact_fwd(z, 1, mean, rstd, gamma, beta, 0.1, p_, sd, out=out, q8=(a8, tab[0, 0:1], tab[0, 1:2])), reps)
+                print(f"normact fwd (p={p_}) + e4m3 copy {name:8s} {ms*1e3:9.1f} us  {2.5*nb/ms/1e6:8.1f} GB/s (2.5 passes)")
+            ms = timeit(lambda: ops.normact_bwd(z, da, 1, mean, rstd, gamma, beta, 0.1, 0.05, 1234, True, True, q8=(a8, tab[0, 0:1], tab[0, 1:2])), reps)
+            print(f"normact bwd (all) + e4m3 copy {name:10s} {ms*1e3:9.1f} us  {5.5*nb/ms/1e6:8.1f} GB/s (5.5 passes)")
+            ms = timeit(lambda: ops.cast_fp8(z, tab[0, 0:1], tab[0, 1:2]), reps)
+            print(f"cast_fp8 (one pass, gathers) {name:11s} {ms*1e3:9.1f} us  {1.5*nb/ms/1e6:8.1f} GB/s (1.5 passes)")
         ms = timeit(lambda: ops.channel_stats(z, 1), reps)
         print(f"channel_stats       {name:16s} {ms*1e3:9.1f} us  {nb/ms/1e6:8.1f} GB/s (1 pass)")
         ms = timeit(lambda: ops.normact_bwd(z, da, 1, mean, rstd, gamma, beta, 0.1, 0.05, 1234, True, True), reps)

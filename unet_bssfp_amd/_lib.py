@@ -56,7 +56,7 @@ class NormActDesc(C.Structure):
                 ("da", _vp), ("ldda", _i32), ("dz", _vp), ("lddz", _i32),
                 ("part", _vp), ("blocks_per_group", _i32), ("sums", _vp), ("batch_stats", _i32),
                 ("s2d_a", _i32), ("s2d_da", _i32), ("sd", _i32), ("sh", _i32), ("sw", _i32), ("seed_ptr", _vp),
-                ("n_affine", _i32)]
+                ("n_affine", _i32), ("q8", _vp), ("ld8", _i32), ("q_use", _vp), ("q_next", _vp)]
 
 
 class NormSmallDesc(C.Structure):
@@ -118,6 +118,8 @@ _SIGNATURES = {
     "mi355_amax_f32": (C.c_int, [_vp, _i64, _vp, _vp]),
     "mi355_amax_act": (C.c_int, [_vp, _i32, _i32, _i64, _i32, _vp, _vp]),
     "mi355_cast_fp8": (C.c_int, [_vp, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _vp]),
+    "mi355_cast_fp8_delayed": (C.c_int, [_vp, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "mi355_fp8_scale_roll": (C.c_int, [_vp, _i32, _vp]),
     "mi355_fp8_selftest": (C.c_int, [_vp, _vp]),
 }
 

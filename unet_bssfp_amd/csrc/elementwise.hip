@@ -361,6 +361,39 @@ __device__ __forceinline__ unsigned drop_keep_mask(unsigned long long seed, unsi
   return m;
 }
 
+// ---- e4m3 copies written by the PRODUCER of an fp8 convolution's operand (delayed per-tensor scaling) ----
+// block maximum -> at most one atomic per workgroup, and none when the tensor-wide maximum is already there (m >= 0: bit
+// order = value order).  Every thread of a 256-thread workgroup calls it.  One atomic per WAVE was measured to double
+// the kernels: all waves finish together and ~6 ns per same-address atomic serialise behind each other.
+__device__ __forceinline__ void amax_commit(float m, float* out) {
+  __shared__ float red[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const unsigned cur = __hip_atomic_load(reinterpret_cast<unsigned int*>(out), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__float_as_uint(m) > cur) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+  }
+}
+// 8 results that are about to be stored as bf16 -> the 8 e4m3 bytes mi355_cast_fp8 would make of the stored tensor
+// (rounded through bf16 first, then * 224 / amax); returns max |bf16 value| for the next step's scale
+__device__ __forceinline__ float e4m3_piece(const float (&f)[8], float sc, uint8_t* dst) {
+  float m = 0.f, r[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float b = __uint_as_float((uint32_t)f32_to_bf16_bits(f[j]) << 16);
+    m = fmaxf(m, fabsf(b));
+    r[j] = b * sc;
+  }
+  uint32_t w0 = cvt_pk_fp8(r[0], r[1], 0u, false), w1 = cvt_pk_fp8(r[4], r[5], 0u, false);
+  w0 = cvt_pk_fp8(r[2], r[3], w0, true);
+  w1 = cvt_pk_fp8(r[6], r[7], w1, true);
+  *reinterpret_cast<uint2*>(dst) = make_uint2(w0, w1);
+  return m;
+}
+
 struct NormActArgs {
   const char* z; int ldz; char* a; int lda;
   int c; long long rows_per_group; int groups;
@@ -371,6 +404,7 @@ struct NormActArgs {
   int n_affine;   // entries of gamma / beta
   S2D s2d_a;      // forward: write `a` in space-to-depth layout
   S2D s2d_da;     // backward: read `da` from a space-to-depth tensor
+  uint8_t* q8; int ld8; const float* q_use; float* q_next;   // e4m3 copy of a (fwd) / dz (bwd_apply), bf16 with c == 32 only
 };
 
 template <typename T, bool DROP>
@@ -396,6 +430,8 @@ __global__ __launch_bounds__(256) void normact_fwd_kernel(const NormActArgs q) {
   const T* zb = reinterpret_cast<const T*>(q.z) + (long long)g * q.rows_per_group * q.ldz;
   T* ab = reinterpret_cast<T*>(q.a) + (long long)g * q.rows_per_group * q.lda;
   const long long stride = (long long)gridDim.x * rpp;
+  const float sc8 = q.q8 ? fp8_scale_of(q.q_use) : 1.f;
+  float m8 = 0.f;
   for (long long row = (long long)blockIdx.x * rpp + rsub; row < q.rows_per_group; row += stride) {
     Vec16<T> v;
     v.load(zb + row * q.ldz + ch0);
@@ -414,6 +450,12 @@ __global__ __launch_bounds__(256) void normact_fwd_kernel(const NormActArgs q) {
       v.store(reinterpret_cast<T*>(q.a) + srow * q.lda + (long long)blk * q.s2d_a.cblk + ch0);
       s2d_zero_siblings<T>(reinterpret_cast<T*>(q.a), q.s2d_a, srow, blk, border, q.lda, ch0);
     } else v.store(ab + row * q.lda + ch0);
+    if constexpr (sizeof(T) == 2) {
+      if (q.q8) m8 = fmaxf(m8, e4m3_piece(v.f, sc8, q.q8 + ((long long)g * q.rows_per_group + row) * q.ld8 + ch0));
+    }
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (q.q8) amax_commit(m8, q.q_next);      // (c == 32: every lane of the wave is here)
   }
 }
 
@@ -525,6 +567,8 @@ __global__ __launch_bounds__(256) void normact_bwd_apply_kernel(const NormActArg
   const T* db = reinterpret_cast<const T*>(q.da) + (long long)g * q.rows_per_group * q.ldda;
   T* ob = reinterpret_cast<T*>(q.dz) + (long long)g * q.rows_per_group * q.lddz;
   const long long stride = (long long)gridDim.x * rpp;
+  const float sc8 = q.q8 ? fp8_scale_of(q.q_use) : 1.f;
+  float m8 = 0.f;
   for (long long row = (long long)blockIdx.x * rpp + rsub; row < q.rows_per_group; row += stride) {
     Vec16<T> zv, dv;
     zv.load(zb + row * q.ldz + ch0);
@@ -539,6 +583,12 @@ __global__ __launch_bounds__(256) void normact_bwd_apply_kernel(const NormActArg
       zv.f[j] = kk[j] * (gv - m0[j] - xh * m1[j]);
     }
     zv.store(ob + row * q.lddz + ch0);
+    if constexpr (sizeof(T) == 2) {
+      if (q.q8) m8 = fmaxf(m8, e4m3_piece(zv.f, sc8, q.q8 + ((long long)g * q.rows_per_group + row) * q.ld8 + ch0));
+    }
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (q.q8) amax_commit(m8, q.q_next);
   }
 }
 
@@ -1338,6 +1388,10 @@ static int fill_normact(const mi355_normact_desc* d, NormActArgs* q, const char*
   q->part = d->part; q->blocks_per_group = d->blocks_per_group; q->sums = d->sums; q->batch_stats = d->batch_stats;
   q->s2d_a = S2D{0, 0, 0, 0};
   q->s2d_da = S2D{0, 0, 0, 0};
+  MI355_REQUIRE(!d->q8 || (d->dtype == MI355_DT_BF16 && d->c == 32 && d->ld8 >= d->c && d->ld8 % 8 == 0 && d->q_use && d->q_next &&
+                           !d->s2d_a && !d->s2d_da),
+                "%s: the e4m3 copy is written for plain bf16 tensors of 32 channels (q8, q_use, q_next)", who);
+  q->q8 = (uint8_t*)d->q8; q->ld8 = d->ld8; q->q_use = d->q_use; q->q_next = d->q_next;
   if (d->s2d_a || d->s2d_da) {
     MI355_REQUIRE((long long)d->sd * d->sh * d->sw * (d->groups == 1 ? 1 : 1) > 0 &&
                   ((long long)d->rows_per_group * d->groups) % ((long long)d->sd * d->sh * d->sw) == 0,
@@ -1570,11 +1624,6 @@ int mi355_mfma_selftest(float* out_f32_1024, float* out_bf16_1024, void* stream)
 
 namespace {
 // ------------------------------------------------------------------ fp8 operand preparation
-__device__ __forceinline__ void amax_commit(float m, float* out) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));   // m >= 0: bit order = value order
-}
 __global__ __launch_bounds__(256) void amax_f32_kernel(const float* __restrict__ x, long long n, float* out) {
   float m = 0.f;
   const long long stride = (long long)gridDim.x * 256 * 4;
@@ -1607,11 +1656,13 @@ __global__ __launch_bounds__(256) void amax_act_kernel(const T* __restrict__ x, 
 // 16 channels per thread: two 16-B loads of bf16 (four of f32), one 16-B store of e4m3
 template <typename T>
 __global__ __launch_bounds__(256) void cast_fp8_kernel(const T* __restrict__ x, int ld, int c, long long rows,
-                                                        const float* __restrict__ amax, uint8_t* __restrict__ dst, int ld_dst) {
+                                                        const float* __restrict__ amax, uint8_t* __restrict__ dst, int ld_dst,
+                                                        float* __restrict__ next) {
   constexpr int EPV = Elem<T>::kPer16B, NV = 16 / EPV;
   const float sc = fp8_scale_of(amax);
   const int gpr = c / 16;
   const long long total = rows * gpr, stride = (long long)gridDim.x * 256;
+  float m = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
     const long long row = i / gpr;
     const int g = (int)(i - row * gpr);
@@ -1621,7 +1672,10 @@ __global__ __launch_bounds__(256) void cast_fp8_kernel(const T* __restrict__ x, 
       Vec16<T> v;
       v.load(x + row * ld + g * 16 + k * EPV);
 #pragma unroll
-      for (int j = 0; j < EPV; ++j) f[k * EPV + j] = v.f[j] * sc;
+      for (int j = 0; j < EPV; ++j) {
+        m = fmaxf(m, fabsf(v.f[j]));
+        f[k * EPV + j] = v.f[j] * sc;
+      }
     }
     uint32_t w[4];
 #pragma unroll
@@ -1631,6 +1685,15 @@ __global__ __launch_bounds__(256) void cast_fp8_kernel(const T* __restrict__ x, 
     }
     *reinterpret_cast<uint4*>(dst + row * ld_dst + g * 16) = make_uint4(w[0], w[1], w[2], w[3]);
   }
+  if (next) amax_commit(m, next);
+}
+// delayed scaling: the amax gathered during a step becomes the scale of the next one
+__global__ void fp8_scale_roll_kernel(float* __restrict__ table, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float nx = table[2 * i + 1];
+  if (nx > 0.f) table[2 * i] = nx;
+  table[2 * i + 1] = 0.f;
 }
 // D[i][j] = sum_k A[i][k] B[k][j], 32 x 32 x 64, A[i][k] = ((i + k) % 5) - 2, B[k][j] = ((2 k + j) % 7) - 3 (exact in e4m3)
 __global__ void fp8_selftest_kernel(float* out) {
@@ -1687,14 +1750,25 @@ int mi355_amax_act(const void* x, int32_t ld, int32_t c, int64_t rows, int32_t d
 
 int mi355_cast_fp8(const void* src, int32_t ld_src, int32_t c, int64_t rows, int32_t src_dtype, const float* amax,
                    void* dst, int32_t ld_dst, void* stream) {
+  return mi355_cast_fp8_delayed(src, ld_src, c, rows, src_dtype, amax, nullptr, dst, ld_dst, stream);
+}
+
+int mi355_fp8_scale_roll(float* table, int32_t n, void* stream) {
+  MI355_REQUIRE(table && n > 0, "fp8_scale_roll: bad argument");
+  hipLaunchKernelGGL(fp8_scale_roll_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, (int)n);
+  return mi355_check_launch("fp8_scale_roll");
+}
+
+int mi355_cast_fp8_delayed(const void* src, int32_t ld_src, int32_t c, int64_t rows, int32_t src_dtype, const float* amax,
+                           float* amax_next, void* dst, int32_t ld_dst, void* stream) {
   MI355_REQUIRE(src && dst && amax && rows > 0 && ld_dst >= c && ld_dst % 16 == 0, "cast_fp8: bad argument");
   int rc = check_rows(c, ld_src, src_dtype, "cast_fp8");
   if (rc) return rc;
   long long nb = (rows * (c / 16) + 256 * 4 - 1) / (256 * 4);
   if (nb > 2048) nb = 2048;
   if (nb < 1) nb = 1;
-  if (src_dtype == MI355_DT_F32) hipLaunchKernelGGL(cast_fp8_kernel<float>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float*)src, ld_src, c, (long long)rows, amax, (uint8_t*)dst, ld_dst);
-  else hipLaunchKernelGGL(cast_fp8_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ld_src, c, (long long)rows, amax, (uint8_t*)dst, ld_dst);
+  if (src_dtype == MI355_DT_F32) hipLaunchKernelGGL(cast_fp8_kernel<float>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float*)src, ld_src, c, (long long)rows, amax, (uint8_t*)dst, ld_dst, amax_next);
+  else hipLaunchKernelGGL(cast_fp8_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ld_src, c, (long long)rows, amax, (uint8_t*)dst, ld_dst, amax_next);
   return mi355_check_launch("cast_fp8");
 }
 

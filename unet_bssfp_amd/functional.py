@@ -190,6 +190,84 @@ class SideStream:
 
 
 # ====================================================================================== layout
+class Fp8Scales:
+    """Delayed per-tensor scaling of the e4m3 operands (BASELINE.json configs[4]).  An operand's scale 224 / amax has to be
+    known when its PRODUCER writes it, if the producer is to write the e4m3 copy itself (no amax pass, no cast pass over the
+    tensor): every (layer, operand role) owns a slot = (amax in use, amax being gathered) in one device table; kernels that
+    write or cast an operand scale with the first and raise the second; ``advance`` (once per training step, on the device:
+    part of a captured step) makes the gathered amax the one in use.  A slot's first step has no history: it takes the
+    in-step amax pass (``primed`` is host state, it changes only between steps).  Values beyond twice the previous step's
+    amax saturate at +-448 (e4m3 holds 448, the scale maps amax to 224)."""
+    ROWS = 256
+    _chunks = {}      # device -> [(table f32 [ROWS, 2], [slots])]
+    producer_side = True     # False: every operand takes the consumer-side cast (diagnostics / A-B)
+
+    class Slot:
+        __slots__ = ("use", "next", "primed", "touched")
+
+        def __init__(self, row: torch.Tensor):
+            self.use, self.next = row[0:1], row[1:2]
+            self.primed = self.touched = False
+
+    @classmethod
+    def slot(cls, device) -> "Fp8Scales.Slot":
+        chunks = cls._chunks.setdefault(device, [])
+        if not chunks or len(chunks[-1][1]) == cls.ROWS:
+            chunks.append((torch.zeros((cls.ROWS, 2), dtype=torch.float32, device=device), []))
+        table, slots = chunks[-1]
+        s = cls.Slot(table[len(slots)])
+        slots.append(s)
+        return s
+
+    @classmethod
+    def advance(cls, device):
+        for table, slots in cls._chunks.get(device, ()):
+            if any(s.touched for s in slots):
+                ops.fp8_scale_roll(table, len(slots))
+                for s in slots:
+                    s.primed, s.touched = s.primed or s.touched, False
+        Fp8Side.clear()
+
+
+class Fp8Side:
+    """e4m3 copies on their way from the kernel that wrote them to the convolution that consumes them, keyed by the bf16
+    tensor they mirror (autograd hands tensors, not attributes, from one node to the next).  An entry keeps its bf16 tensor
+    alive, so the address cannot come to mean another tensor while the entry exists.  Emptied every step."""
+    _by_ptr = {}
+
+    @classmethod
+    def put(cls, t: torch.Tensor, t8: torch.Tensor):
+        cls._by_ptr[t.data_ptr()] = (t8, tuple(t.shape), t)
+
+    @classmethod
+    def take(cls, t: torch.Tensor, keep: bool = False) -> Optional[torch.Tensor]:
+        hit = cls._by_ptr.get(t.data_ptr()) if keep else cls._by_ptr.pop(t.data_ptr(), None)
+        return hit[0] if hit is not None and hit[1] == tuple(t.shape) else None
+
+    @classmethod
+    def clear(cls):
+        cls._by_ptr.clear()
+
+
+def fp8_operand(x: torch.Tensor, slot: "Fp8Scales.Slot", constant: bool = False) -> torch.Tensor:
+    """The e4m3 copy of a convolution operand with the amax in ``slot.use``: the one its producer wrote if there is one;
+    otherwise one cast pass with the previous step's amax (gathering this step's); on the slot's first step the in-step
+    amax pass + cast.  constant: an input that enters several convolution calls of one step (the packed batch) is cast once."""
+    x8 = Fp8Side.take(x, keep=constant)
+    if x8 is not None:
+        return x8
+    if slot.primed:
+        x8 = ops.cast_fp8(x, slot.use, slot.next)
+    else:
+        ops.amax_act(x, out=slot.use)
+        torch.maximum(slot.next, slot.use, out=slot.next)
+        x8 = ops.cast_fp8(x, slot.use)
+    slot.touched = True
+    if constant:
+        Fp8Side.put(x, x8)
+    return x8
+
+
 class PackMemo:
     """Packed form of constant NCDHW inputs, valid within ONE training step (``clear()`` runs at the start of every
     step, so a benchmark that feeds the same batch again still packs it each step).  An entry is tied to the tensor
@@ -208,6 +286,11 @@ class PackMemo:
         if len(cls._store) >= 8:
             cls._store.clear()
         cls._store[(id(x), cp, dtype)] = (weakref.ref(x), x._version, act)
+
+    @classmethod
+    def holds(cls, act) -> bool:
+        """is ``act`` the packed form of a constant input of this step?"""
+        return any(e[2].data_ptr() == act.data_ptr() for e in cls._store.values())
 
     @classmethod
     def clear(cls):
@@ -318,6 +401,14 @@ class ConvSpec:
             w.detach(), self.cin, self.cout, k, k ** 3, self.cin * k ** 3, (k * k, k, 1), (k - 1,) * 3, (-1,) * 3,
             dtype, cinp, reuse=r))
 
+    def fp8_slot(self, role: str, device) -> "Fp8Scales.Slot":
+        """delayed-scaling state of this layer's e4m3 operand: role 'x' (forward input) or 'g' (incoming gradient)"""
+        slots = self.__dict__.setdefault("_fp8_slots", {})
+        key = (role, device)
+        if key not in slots:
+            slots[key] = Fp8Scales.slot(device)
+        return slots[key]
+
     # e4m3 packings (per-tensor scale 224 / max |w|): value = (packed, coutp, cinp, amax)
     def _fp8(self, key, w, builder):
         def build(reuse):
@@ -417,9 +508,9 @@ class ConvFn(Function):
               and dtype == torch.bfloat16 and ops.conv_fp8_supported(x0, round_up(spec.cout, 32), out, (do_, ho, wo))):
             # BASELINE.json configs[4]: e4m3 operands (per-tensor scales) on the block-scaled MFMA, f32 accumulate, bf16 out
             wp, coutp, _, amax_w = spec.w_fwd8(weight, c0)
-            amax_x = ops.amax_act(x0)
-            x8 = ops.cast_fp8(x0, amax_x)
-            q = (amax_x, amax_w)
+            slot = spec.fp8_slot("x", dev)
+            x8 = fp8_operand(x0, slot, constant=not x0.requires_grad and PackMemo.holds(x0))
+            q = (slot.use, amax_w)
             bp = bias.detach() if bias is not None else None
             if want_stats:
                 tiles, _ = ops.conv_num_tiles(x8, None, wp, coutp, 3, 1, (1, 1, 1), out, (do_, ho, wo), fp8=q)
@@ -486,9 +577,9 @@ class ConvFn(Function):
             elif (ctx.fp8 and spec.kind == "conv" and k == 3 and spec.stride == 1 and spec.pad == 1 and dtype == torch.bfloat16
                   and ops.conv_fp8_supported(dz, round_up(c0 + c1, 32), dxc, (di, hi, wi))):
                 wp, coutp, _, amax_w = spec.w_dgrad8(weight, cg)
-                amax_g = ops.amax_act(dz)
-                ops.conv_fwd(ops.cast_fp8(dz, amax_g), None, wp, coutp, None, 3, 1, (1, 1, 1), dxc, (di, hi, wi),
-                             real=(spec.cout, spec.cin), fp8=(amax_g, amax_w))
+                slot = spec.fp8_slot("g", dev)
+                ops.conv_fwd(fp8_operand(dz, slot), None, wp, coutp, None, 3, 1, (1, 1, 1), dxc, (di, hi, wi),
+                             real=(spec.cout, spec.cin), fp8=(slot.use, amax_w))
             elif spec.kind == "conv" and spec.stride == 1:
                 wp, coutp, _ = spec.w_dgrad_s1(weight, dtype, cg, c0 + c1)
                 ops.conv_fwd(dz, None, wp, coutp, None, k, 1, (k - 1 - spec.pad,) * 3, dxc, (di, hi, wi),
@@ -592,6 +683,7 @@ class DropoutState:
         cls.base(device).add_(1)
         cls._salt = 0
         PackMemo.clear()                    # a new training step: constant inputs are packed afresh
+        Fp8Scales.advance(device)           # ... and the e4m3 scales gathered in the last step come into use
 
     @classmethod
     def reset(cls):
@@ -604,10 +696,13 @@ class NormActFn(Function):
 
     @staticmethod
     def forward(ctx, z, part, gamma, beta, conv_bias, cfg: NormCfg, training, running_mean, running_var,
-                s2d_out: bool = False, batches_tracked=None, small: bool = False, bn_groups: int = 1):
+                s2d_out: bool = False, batches_tracked=None, small: bool = False, bn_groups: int = 1,
+                emit8=None, emit8_bwd=None):
         """bn_groups > 1: BatchNorm statistics per consecutive sample group (two forward calls of the discriminator stacked
         along the batch: each group is normalised with its own batch statistics, the running statistics receive the groups'
         momentum updates in order -- exactly what two separate calls do)."""
+        # emit8 / emit8_bwd (Fp8Scales.Slot or None): the fp8 convolution after this node / the fp8 data gradient of the
+        # convolution before it reads an e4m3 copy of a / dz: the kernel that writes the bf16 tensor writes the copy too
         z = ops.as_act(z)
         n, d, h, w, c = z.shape
         rows = n * d * h * w
@@ -616,6 +711,9 @@ class NormActFn(Function):
         mean = rstd = None
         batch_stats = False
         ctx.small = False
+        ctx.emit8_bwd = emit8_bwd if (emit8_bwd is not None and emit8_bwd.primed and not small and not s2d_out) else None
+        if emit8 is not None and not (emit8.primed and not small and not s2d_out and z.dtype == torch.bfloat16 and c == 32):
+            emit8 = None
         if small and cfg.kind != "none" and (cfg.kind == "instance" or training or running_mean is None):
             # small tensor (low U-Net levels, last PatchGAN blocks): statistics, norm, dropout and activation in ONE launch
             if rows // groups <= 1:
@@ -667,6 +765,11 @@ class NormActFn(Function):
         if s2d_out:
             out = _new_s2d(ops.s2d_shape(n, d, h, w, c), z.dtype, z.device)
             a = ops.normact_fwd(z, groups, mean, rstd, gp, bp, cfg.slope, p, seed, out=out, s2d=True, seed_t=seed_t)
+        elif emit8 is not None:
+            a8 = torch.empty(z.shape, dtype=torch.uint8, device=z.device)
+            a = ops.normact_fwd(z, groups, mean, rstd, gp, bp, cfg.slope, p, seed, seed_t=seed_t, q8=(a8, emit8.use, emit8.next))
+            emit8.touched = True
+            Fp8Side.put(a, a8)
         else:
             a = ops.normact_fwd(z, groups, mean, rstd, gp, bp, cfg.slope, p, seed, seed_t=seed_t)
         ctx.s2d_out = s2d_out
@@ -685,8 +788,16 @@ class NormActFn(Function):
         want_affine = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
         gamma_p, beta_p = ctx.affine_params
         sink = sink_of(gamma_p) if (ctx.needs_input_grad[2] and ctx.needs_input_grad[3] and mean is not None) else None
+        slot8 = ctx.emit8_bwd if (not ctx.small and z.dtype == torch.bfloat16 and z.shape[4] == 32) else None
+        q8 = (torch.empty(z.shape, dtype=torch.uint8, device=z.device), slot8.use, slot8.next) if slot8 is not None else None
+
+        def done(dz):
+            if q8 is not None:
+                slot8.touched = True
+                Fp8Side.put(dz, q8[0])
+            return dz
         if ctx.small:
-            none11 = (None,) * 12
+            none11 = (None,) * 14
             if sink is not None and sink_of(beta_p) is sink:
                 dz, _, _ = ops.normact_small_bwd(z, da, groups, mean, rstd, gp, bp, slope, p, seed, batch_stats, s2d=ctx.s2d_out,
                                                  seed_t=ctx.seed_t, affine_into=(sink_grad(gamma_p), sink_grad(beta_p)),
@@ -698,20 +809,20 @@ class NormActFn(Function):
                                                       s2d=ctx.s2d_out, seed_t=ctx.seed_t, want_affine=want_affine)
             dg = dgamma[:nch].contiguous() if (dgamma is not None and ctx.needs_input_grad[2]) else None
             dbt = dbeta[:nch].contiguous() if (dbeta is not None and ctx.needs_input_grad[3]) else None
-            return (dz, None, dg, dbt) + (None,) * 9
+            return (dz, None, dg, dbt) + (None,) * 11
         if sink is not None and sink_of(beta_p) is sink:
             # both affine gradients straight into the parameters' .grad storage (gradsink.py)
             dz, _, _ = ops.normact_bwd(z, da, groups, mean, rstd, gp, bp, slope, p, seed, batch_stats, True,
                                        s2d=ctx.s2d_out, seed_t=ctx.seed_t, affine_into=(sink_grad(gamma_p), sink_grad(beta_p)),
-                                       accumulate=not sink.fresh(gamma_p))
+                                       accumulate=not sink.fresh(gamma_p), q8=q8)
             sink.written(gamma_p)
             sink.written(beta_p)
-            return dz, None, None, None, None, None, None, None, None, None, None, None, None
+            return (done(dz),) + (None,) * 14
         dz, dgamma, dbeta = ops.normact_bwd(z, da, groups, mean, rstd, gp, bp, slope, p, seed, batch_stats,
-                                            want_affine and mean is not None, s2d=ctx.s2d_out, seed_t=ctx.seed_t)
+                                            want_affine and mean is not None, s2d=ctx.s2d_out, seed_t=ctx.seed_t, q8=q8)
         dg = dgamma[:nch].contiguous() if (dgamma is not None and ctx.needs_input_grad[2]) else None
         dbt = dbeta[:nch].contiguous() if (dbeta is not None and ctx.needs_input_grad[3]) else None
-        return dz, None, dg, dbt, None, None, None, None, None, None, None, None, None
+        return (done(dz), None, dg, dbt) + (None,) * 11
 
 
 # ====================================================================================== pool / loss

@@ -297,13 +297,24 @@ class Convolution(_Mi355Module):
         self.adn = _ADN(cout)
         self.cfg = Fn.NormCfg("instance", cout, eps=eps, slope=slope, p=float(dropout or 0.0))
 
-    def forward_act(self, x0, x1=None):
+    def forward_act(self, x0, x1=None, feeds: Optional[Conv3d] = None):
+        """feeds: the convolution that consumes the result (fp8 mode: the norm kernel writes its e4m3 operand as well)"""
         n, d, h, w = x0.shape[:4]
+        cp = round_up(self.conv.out_channels, 16)
         # small levels (16^3, 8^3): the norm kernel computes the instance statistics itself, in one launch
-        small = ops.norm_is_small(n, d, h, w, round_up(self.conv.out_channels, 16))
+        small = ops.norm_is_small(n, d, h, w, cp)
         z, part = self.conv.forward_act(x0, x1, want_stats=not small, zero_bias_grad=True)
+        emit8 = emit8_bwd = None
+        if cp == 32 and z.dtype == torch.bfloat16 and Fn.Fp8Scales.producer_side:
+            # BASELINE.json configs[4]: e4m3 operands come from the kernel that produces the bf16 tensor (delayed scaling)
+            if feeds is not None and feeds.fp8 and ops.conv_fp8_layer_ok(n, d, h, w, cp, feeds.out_channels):
+                emit8 = feeds.spec.fp8_slot("x", z.device)
+            cin = x0.shape[4] + (x1.shape[4] if x1 is not None else 0)
+            if (self.conv.fp8 and torch.is_grad_enabled() and (x0.requires_grad or (x1 is not None and x1.requires_grad))
+                    and ops.conv_fp8_layer_ok(n, d, h, w, cp, cin)):
+                emit8_bwd = self.conv.spec.fp8_slot("g", z.device)
         return Fn.NormActFn.apply(z, part if not small else None, self.adn.N.weight, self.adn.N.bias, self.conv.bias, self.cfg,
-                                  self.training, None, None, False, None, small)
+                                  self.training, None, None, False, None, small, 1, emit8, emit8_bwd)
 
 
 class TwoConv(_Mi355Module):
@@ -313,7 +324,7 @@ class TwoConv(_Mi355Module):
         self.conv_1 = Convolution(cout, cout, dropout)
 
     def forward_act(self, x0, x1=None):
-        return self.conv_1.forward_act(self.conv_0.forward_act(x0, x1))
+        return self.conv_1.forward_act(self.conv_0.forward_act(x0, x1, feeds=self.conv_1.conv))
 
 
 class Down(_Mi355Module):

@@ -308,22 +308,60 @@ def amax_f32(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tenso
     return out
 
 
-def amax_act(x: torch.Tensor) -> torch.Tensor:
-    require_cuda(x)
+def amax_act(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    require_cuda(x, out)
     n, d, h, w, c = x.shape
-    out = torch.empty((1,), dtype=torch.float32, device=x.device)
+    out = torch.empty((1,), dtype=torch.float32, device=x.device) if out is None else out
     _lib.check(_lib.load().mi355_amax_act(x.data_ptr(), act_ld(x), c, n * d * h * w, _DT[x.dtype], out.data_ptr(), _stream()), "amax_act")
     return out
 
 
-def cast_fp8(x: torch.Tensor, amax: torch.Tensor) -> torch.Tensor:
-    """NDHWC activation -> e4m3 bytes of x * 224 / amax (uint8 tensor of the same shape, one byte per channel)."""
-    require_cuda(x, amax)
+def cast_fp8(x: torch.Tensor, amax: torch.Tensor, amax_next: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """NDHWC activation -> e4m3 bytes of x * 224 / amax (uint8 tensor of the same shape, one byte per channel).
+    amax_next (delayed scaling): raised to max |x| in the same pass -- `amax` is then the previous step's."""
+    require_cuda(x, amax, amax_next)
     n, d, h, w, c = x.shape
     out = torch.empty((n, d, h, w, c), dtype=torch.uint8, device=x.device)
-    _lib.check(_lib.load().mi355_cast_fp8(x.data_ptr(), act_ld(x), c, n * d * h * w, _DT[x.dtype], amax.data_ptr(), out.data_ptr(), c,
-                                          _stream()), "cast_fp8")
+    _lib.check(_lib.load().mi355_cast_fp8_delayed(x.data_ptr(), act_ld(x), c, n * d * h * w, _DT[x.dtype], amax.data_ptr(),
+                                                  _ptr(amax_next), out.data_ptr(), c, _stream()), "cast_fp8")
     return out
+
+
+def fp8_scale_roll(table: torch.Tensor, n: int):
+    """table f32 [rows][2] = (amax in use, amax being gathered): the first n rows start a new training step."""
+    require_cuda(table)
+    assert table.dtype == torch.float32 and table.is_contiguous() and table.shape[1] == 2 and 0 < n <= table.shape[0]
+    _lib.check(_lib.load().mi355_fp8_scale_roll(table.data_ptr(), n, _stream()), "fp8_scale_roll")
+
+
+def conv_fp8_layer_ok(n: int, d: int, h: int, w: int, c_in: int, c_out: int) -> bool:
+    """conv_fp8_supported for a layer known by its shapes only (bf16 NDHWC tensors with the channel counts stored):
+    lets the PRODUCER of the operand decide whether to write the e4m3 copy."""
+    if c_in != 32:
+        return False
+    key = (n, d, h, w, c_in, c_out)
+    hit = _FP8_OK.get(key)
+    if hit is None:
+        d_ = _lib.ConvDesc()
+        d_.x0, d_.c0, d_.ld0 = 256, c_in, c_in
+        d_.x1, d_.c1, d_.ld1 = None, 0, 0
+        d_.n, d_.di, d_.hi, d_.wi = n, d, h, w
+        d_.do_, d_.ho, d_.wo = d, h, w
+        d_.ks, d_.stride = 3, 1
+        d_.pad = (C.c_int32 * 3)(1, 1, 1)
+        d_.wp, d_.coutp = 256, round_up(c_out, 32)
+        co = round_up(c_out, 16)
+        d_.y, d_.ldy, d_.cstore = 256, co, co
+        d_.dy, d_.hy, d_.wy = d, h, w
+        d_.os = 1
+        d_.ooff = (C.c_int32 * 3)(0, 0, 0)
+        d_.dtype = DT_FP8
+        d_.q_amax_x = d_.q_amax_w = 256
+        hit = _FP8_OK[key] = _lib.load().mi355_conv_plan_id(C.byref(d_)) > 0
+    return hit
+
+
+_FP8_OK = {}
 
 
 def conv_fp8_supported(x0: torch.Tensor, coutp: int, out: torch.Tensor, grid) -> bool:
@@ -426,13 +464,24 @@ def _norm_probe(kind, z, gamma):
     return NORM_PROBE(kind, gamma.numel() if gamma is not None else c, n * dd * h * w, z.element_size())
 
 
-def normact_fwd(z, groups, mean, rstd, gamma, beta, slope, drop_p=0.0, seed=0, out=None, s2d=False, seed_t=None):
-    """s2d=True: `out` is the space-to-depth tensor S(a) (s2d_shape) instead of a plain one; every slot of it is written."""
+def _set_q8(d, q8):
+    """q8 = (e4m3 tensor to write [uint8, shape of the result], amax in use f32[1], amax being gathered f32[1])"""
+    t8, use, nxt = q8
+    require_cuda(t8, use, nxt)
+    assert t8.dtype == torch.uint8 and t8.is_contiguous() and use.dtype == nxt.dtype == torch.float32
+    d.q8, d.ld8, d.q_use, d.q_next = t8.data_ptr(), t8.shape[-1], use.data_ptr(), nxt.data_ptr()
+
+
+def normact_fwd(z, groups, mean, rstd, gamma, beta, slope, drop_p=0.0, seed=0, out=None, s2d=False, seed_t=None, q8=None):
+    """s2d=True: `out` is the space-to-depth tensor S(a) (s2d_shape) instead of a plain one; every slot of it is written.
+    q8: also write the e4m3 copy of the result for the fp8 convolution that consumes it (see _set_q8)."""
     require_cuda(z, mean, rstd, gamma, beta, out)
     if out is None:
         out = torch.empty(z.shape, dtype=z.dtype, device=z.device)
     d = _normact_desc(z, groups, mean, rstd, gamma, beta, slope, drop_p, seed, seed_t)
     d.a, d.lda = out.data_ptr(), act_ld(out)
+    if q8 is not None:
+        _set_q8(d, q8)
     if s2d:
         d.s2d_a = 1
         d.sd, d.sh, d.sw = z.shape[1:4]
@@ -444,7 +493,7 @@ def normact_fwd(z, groups, mean, rstd, gamma, beta, slope, drop_p=0.0, seed=0, o
 
 
 def normact_bwd(z, da, groups, mean, rstd, gamma, beta, slope, drop_p, seed, batch_stats, want_affine_grads,
-                s2d=False, seed_t=None, affine_into=None, accumulate=False):
+                s2d=False, seed_t=None, affine_into=None, accumulate=False, q8=None):
     """Returns (dz, dgamma, dbeta).  dgamma/dbeta are f32 [C] (None if there is no norm).
     s2d=True: `da` is a gradient in space-to-depth layout (the forward wrote S(a)).
     affine_into=(dgamma, dbeta): write (accumulate=True: add) the affine gradients into these caller-owned f32
@@ -461,6 +510,8 @@ def normact_bwd(z, da, groups, mean, rstd, gamma, beta, slope, drop_p, seed, bat
     if s2d:
         d.s2d_da = 1
         d.sd, d.sh, d.sw = z.shape[1:4]
+    if q8 is not None:
+        _set_q8(d, q8)                      # e4m3 copy of dz for the fp8 data-gradient convolution
     dgamma = dbeta = None
     keep = []
     after = _norm_probe("bwd", z, gamma)
