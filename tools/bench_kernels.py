@@ -1,5 +1,5 @@
 """Micro-benchmarks of single kernels through the C ABI (HIP-event timing on the launch stream).
-Usage: python tools/bench_kernels.py [conv|wgrad|norm|all] [--dtype bf16|f32] [--reps 20]"""
+Usage: python tools/bench_kernels.py [conv|wgrad|norm|all] [--dtype bf16|f32|fp8 (conv only)] [--reps 20]"""
 import argparse
 import os
 import sys
@@ -35,18 +35,29 @@ def bench_conv(dtype, reps, only=None):
         if only and only not in name:
             continue
         layer = Conv3d(c0 + c1, cout, 3, 1, 1).to(DEV)
-        x0 = torch.randn(1, s, s, s, c0, device=DEV).to(dtype)
-        x1 = torch.randn(1, s, s, s, c1, device=DEV).to(dtype) if c1 else None
-        wp, coutp, _ = layer.spec.w_fwd(layer.weight, dtype, c0 + c1)
-        out = ops.new_act(1, s, s, s, cout, dtype, DEV)
+        fp8 = dtype == "fp8"
+        if fp8 and (c0 != 32 or c1):
+            continue
+        adt = torch.bfloat16 if fp8 else dtype
+        x0 = torch.randn(1, s, s, s, c0, device=DEV).to(adt)
+        x1 = torch.randn(1, s, s, s, c1, device=DEV).to(adt) if c1 else None
+        q = None
+        if fp8:
+            wp, coutp, _, amax_w = layer.spec.w_fwd8(layer.weight, c0)
+            amax_x = ops.amax_act(x0)
+            x0 = ops.cast_fp8(x0, amax_x)
+            q = (amax_x, amax_w)
+        else:
+            wp, coutp, _ = layer.spec.w_fwd(layer.weight, dtype, c0 + c1)
+        out = ops.new_act(1, s, s, s, cout, adt, DEV)
         bias = layer.bias.detach()
-        tiles, _ = ops.conv_num_tiles(x0, x1, wp, coutp, 3, 1, (1, 1, 1), out, (s, s, s))
+        tiles, _ = ops.conv_num_tiles(x0, x1, wp, coutp, 3, 1, (1, 1, 1), out, (s, s, s), fp8=q)
         part = torch.empty((tiles, 2, coutp), dtype=torch.float32, device=DEV)
         plan = []
         ops.CONV_PROBE = lambda pid, d, real: plan.append(pid) and None
-        ops.conv_fwd(x0, x1, wp, coutp, bias, 3, 1, (1, 1, 1), out, (s, s, s), stats=part)
+        ops.conv_fwd(x0, x1, wp, coutp, bias, 3, 1, (1, 1, 1), out, (s, s, s), stats=part, fp8=q)
         ops.CONV_PROBE = None
-        ms = timeit(lambda: ops.conv_fwd(x0, x1, wp, coutp, bias, 3, 1, (1, 1, 1), out, (s, s, s), stats=part), reps)
+        ms = timeit(lambda: ops.conv_fwd(x0, x1, wp, coutp, bias, 3, 1, (1, 1, 1), out, (s, s, s), stats=part, fp8=q), reps)
         fl = 2.0 * (c0 + c1) * cout * 27 * s ** 3
         print(f"conv fwd  {name:28s} {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TFLOP/s   plan {plan[0]}  stat rows {tiles}")
 
@@ -132,7 +143,7 @@ if __name__ == "__main__":
     if a.lib:
         import tools.diaglib as D
         D.use(a.lib)
-    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dt = torch.bfloat16 if a.dtype == "bf16" else ("fp8" if a.dtype == "fp8" else torch.float32)
     torch.manual_seed(0)
     if a.what in ("conv", "all"):
         bench_conv(dt, a.reps, a.only)

@@ -14,7 +14,7 @@ i=0
 for name in SQ1 SQ2 L2A L2B L2C; do
   case $WHICH in sq) [[ $name == SQ* ]] || continue;; l2) [[ $name == L2* ]] || continue;; esac
   set=${!name}
-  timeout -k 10 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/$name -o p -- python3 $ROOT/tools/bench_kernels.py conv --dtype bf16 --reps 5 --only "$ONLY" > $OUT/$name.log 2>&1 || { echo "pass $name failed"; tail -3 $OUT/$name.log; }
+  timeout -k 10 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/$name -o p -- python3 $ROOT/tools/bench_kernels.py conv --dtype ${PMC_DTYPE:-bf16} --reps 5 --only "$ONLY" > $OUT/$name.log 2>&1 || { echo "pass $name failed"; tail -3 $OUT/$name.log; }
 done
 python3 $ROOT/tools/pmc_summary.py $OUT conv_ > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
