@@ -84,6 +84,7 @@ def parse():
                     help="world size > 1: broadcast rank 0's BatchNorm running statistics before every k-th step "
                          "(DDP's broadcast_buffers=True, src/train.py:30; 0 = never)")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch (--gpus N without torch.distributed.run): rendezvous port (0 = pick a free one)")
+    ap.add_argument("--composed-losses", action="store_true", help="developer A/B: BCE / L1 loss heads as composed torch ops instead of the one-launch kernels; reported")
     ap.add_argument("--side-stream", action="store_true", help="developer A/B: weight gradients of the small layers on a second stream (measured slower); reported")
     ap.add_argument("--small-norm-elements", type=int, default=None,
                     help="developer A/B: size limit of the one-launch norm kernels (0 = off); reported")
@@ -421,6 +422,9 @@ def main():
     discr = M.Discriminator("bssfp")
     model = bSSFPToDWITensorModel("bssfp", gen=gen, discr=discr).to(dev).train()
     M.set_compute_dtype(model, dtype)
+    if a.composed_losses:
+        model.fused_loss_heads = False
+        nondefault["composed_losses"] = True
     batch = synthetic_batch(a.batch, a.size, seed=1234 + rank, device=dev)   # resident in HBM
     torch.manual_seed(1000 + rank)                         # dropout seeds differ per rank
     use_graph = not a.no_graph and a.workload == "gan_step"

@@ -308,6 +308,27 @@ int mi355_maxpool2_bwd_add(const void* x, int32_t ldx, const void* y, int32_t ld
 int32_t mi355_l1_blocks(int64_t count);
 int mi355_l1_fwd(const float* a, const float* b, int64_t count, float* partials, float* out, void* stream);
 int mi355_l1_bwd(const float* a, const float* b, int64_t count, const float* gscale, float* da, void* stream);
+/* the partial sums only (mi355_l1_blocks(count) floats): the GAN generator loss below finishes them */
+int mi355_l1_partials(const float* a, const float* b, int64_t count, float* partials, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GAN loss heads on the PatchGAN logit maps (a few hundred values): ONE launch forward, ONE backward, instead of the
+ * ~45 scalar-sized torch launches per step of BCEWithLogits + the loss arithmetic (a launch costs ~5 us in a graph replay).
+ *  _gen_step (src/model.py:126-137):  out4 = { L1 = sum(l1_partials) / count, recon = L1 / recon_divisor * recon_factor,
+ *      adv = mean BCEWithLogits(logits, 1), adv + recon };  bwd: dlogits = upstream[0] (sigmoid(x) - 1) / n and
+ *      l1_gscale[0] = upstream[0] * recon_factor / recon_divisor (the device scalar mi355_l1_bwd takes).
+ *  _discr_step (src/model.py:183-193): out1[0] = (mean BCEWithLogits(real, 1) + mean BCEWithLogits(fake, 0)) / 2;
+ *      bwd: dfake = upstream[0] / 2 * sigmoid(x) / n_fake, dreal = upstream[0] / 2 * (sigmoid(x) - 1) / n_real.
+ * BCEWithLogits(x, t) = (1 - t) x - log_sigmoid(x) (torch's form); sums in f64, everything else f32.
+ * ---------------------------------------------------------------------------------------- */
+int mi355_gan_gen_loss_fwd(const float* logits, int32_t n, const float* l1_partials, int32_t n_partials, int64_t count,
+                           float recon_divisor, float recon_factor, float* out4, void* stream);
+int mi355_gan_gen_loss_bwd(const float* logits, int32_t n, const float* upstream, float recon_divisor, float recon_factor,
+                           float* dlogits, float* l1_gscale, void* stream);
+int mi355_gan_discr_loss_fwd(const float* logits_fake, int32_t n_fake, const float* logits_real, int32_t n_real, float* out1,
+                             void* stream);
+int mi355_gan_discr_loss_bwd(const float* logits_fake, int32_t n_fake, const float* logits_real, int32_t n_real,
+                             const float* upstream, float* dfake, float* dreal, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused multi-tensor AdamW -- torch.optim.AdamW(params, lr) with torch defaults

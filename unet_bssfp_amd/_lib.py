@@ -101,6 +101,11 @@ _SIGNATURES = {
     "mi355_l1_blocks": (_i32, [_i64]),
     "mi355_l1_fwd": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "mi355_l1_bwd": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "mi355_l1_partials": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "mi355_gan_gen_loss_fwd": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _f32, _f32, _vp, _vp]),
+    "mi355_gan_gen_loss_bwd": (C.c_int, [_vp, _i32, _vp, _f32, _f32, _vp, _vp, _vp]),
+    "mi355_gan_discr_loss_fwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp]),
+    "mi355_gan_discr_loss_bwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "mi355_adamw_multi": (C.c_int, [_vp, _vp, _i32, _f32, _f32, _f32, _f32, _f32, _vp, _i64, _vp]),
     "mi355_dti_scalar_maps": (C.c_int, [_vp, _i32, _i64, _i64, _i64, C.c_double, C.c_double,
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -958,6 +958,67 @@ __global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ a
   }
 }
 
+// ------------------------------------------------------------------ GAN loss heads (tiny logit maps: one workgroup)
+// BCEWithLogits element (torch: (1 - t) x - log_sigmoid(x), log_sigmoid(x) = min(x, 0) - log1p(exp(-|x|)))
+__device__ __forceinline__ float bce_logits_elem(float x, float t) {
+  return (1.f - t) * x - (fminf(x, 0.f) - log1pf(expf(-fabsf(x))));
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// block sum in f64 (256 threads), result valid in thread 0
+__device__ __forceinline__ double block_sum_256(double s, double* red) {
+  __syncthreads();
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  return red[0];
+}
+// _gen_step (src/model.py:126-137): out = {L1, recon = L1 / divisor * factor, adv = mean BCE(logits, 1), adv + recon}
+__global__ __launch_bounds__(256) void gan_gen_loss_fwd_kernel(const float* __restrict__ logits, int n, const float* __restrict__ partials,
+                                                               int np, long long count, float divisor, float factor, float* __restrict__ out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < np; i += 256) s += (double)partials[i];
+  const double l1sum = block_sum_256(s, red);
+  s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)bce_logits_elem(logits[i], 1.f);
+  const double bsum = block_sum_256(s, red);
+  if (threadIdx.x == 0) {
+    const float l1 = (float)(l1sum / (double)count), adv = (float)(bsum / (double)n);
+    const float recon = l1 / divisor * factor;
+    out[0] = l1; out[1] = recon; out[2] = adv; out[3] = adv + recon;
+  }
+}
+// upstream[0] = d loss / d out[3]:  dlogits = upstream (sigmoid(x) - 1) / n,  l1_gscale[0] = upstream * factor / divisor
+__global__ __launch_bounds__(256) void gan_gen_loss_bwd_kernel(const float* __restrict__ logits, int n, const float* __restrict__ upstream,
+                                                               float divisor, float factor, float* __restrict__ dlogits,
+                                                               float* __restrict__ l1_gscale) {
+  const float g = upstream[0];
+  for (int i = threadIdx.x; i < n; i += 256) dlogits[i] = (sigmoidf_(logits[i]) - 1.f) * g / (float)n;
+  if (threadIdx.x == 0) l1_gscale[0] = g * factor / divisor;
+}
+// _discr_step (src/model.py:183-193): out[0] = (mean BCE(real, 1) + mean BCE(fake, 0)) / 2
+__global__ __launch_bounds__(256) void gan_discr_loss_fwd_kernel(const float* __restrict__ fake, int n0, const float* __restrict__ real,
+                                                                 int n1, float* __restrict__ out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n0; i += 256) s += (double)bce_logits_elem(fake[i], 0.f);
+  const double s0 = block_sum_256(s, red);
+  s = 0.0;
+  for (int i = threadIdx.x; i < n1; i += 256) s += (double)bce_logits_elem(real[i], 1.f);
+  const double s1 = block_sum_256(s, red);
+  if (threadIdx.x == 0) out[0] = ((float)(s1 / (double)n1) + (float)(s0 / (double)n0)) / 2.f;
+}
+__global__ __launch_bounds__(256) void gan_discr_loss_bwd_kernel(const float* __restrict__ fake, int n0, const float* __restrict__ real,
+                                                                 int n1, const float* __restrict__ upstream, float* __restrict__ dfake,
+                                                                 float* __restrict__ dreal) {
+  const float g = upstream[0] / 2.f;
+  for (int i = threadIdx.x; i < n0; i += 256) dfake[i] = sigmoidf_(fake[i]) * g / (float)n0;
+  for (int i = threadIdx.x; i < n1; i += 256) dreal[i] = (sigmoidf_(real[i]) - 1.f) * g / (float)n1;
+}
+
 // ------------------------------------------------------------------ AdamW (multi-tensor)
 // Tensor pointers travel BY VALUE in the kernel arguments (chunks of kAdamChunk tensors), so the
 // launch needs no device-side table and can be captured into a hipGraph; the step count is read
@@ -1580,6 +1641,44 @@ int mi355_l1_fwd(const float* a, const float* b, int64_t count, float* partials,
   hipLaunchKernelGGL(l1_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, b, (long long)count, partials);
   hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nb, (long long)count, out);
   return mi355_check_launch("l1_fwd");
+}
+
+int mi355_l1_partials(const float* a, const float* b, int64_t count, float* partials, void* stream) {
+  MI355_REQUIRE(a && b && partials && count > 0, "l1_partials: bad argument");
+  hipLaunchKernelGGL(l1_partial_kernel, dim3(mi355_l1_blocks(count)), dim3(256), 0, (hipStream_t)stream, a, b, (long long)count, partials);
+  return mi355_check_launch("l1_partials");
+}
+
+int mi355_gan_gen_loss_fwd(const float* logits, int32_t n, const float* l1_partials, int32_t n_partials, int64_t count,
+                           float recon_divisor, float recon_factor, float* out4, void* stream) {
+  MI355_REQUIRE(logits && l1_partials && out4 && n > 0 && n_partials > 0 && count > 0 && recon_divisor != 0.f, "gan_gen_loss_fwd: bad argument");
+  hipLaunchKernelGGL(gan_gen_loss_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, (int)n, l1_partials, (int)n_partials,
+                     (long long)count, recon_divisor, recon_factor, out4);
+  return mi355_check_launch("gan_gen_loss_fwd");
+}
+
+int mi355_gan_gen_loss_bwd(const float* logits, int32_t n, const float* upstream, float recon_divisor, float recon_factor,
+                           float* dlogits, float* l1_gscale, void* stream) {
+  MI355_REQUIRE(logits && upstream && dlogits && l1_gscale && n > 0 && recon_divisor != 0.f, "gan_gen_loss_bwd: bad argument");
+  hipLaunchKernelGGL(gan_gen_loss_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, (int)n, upstream, recon_divisor,
+                     recon_factor, dlogits, l1_gscale);
+  return mi355_check_launch("gan_gen_loss_bwd");
+}
+
+int mi355_gan_discr_loss_fwd(const float* logits_fake, int32_t n_fake, const float* logits_real, int32_t n_real, float* out1,
+                             void* stream) {
+  MI355_REQUIRE(logits_fake && logits_real && out1 && n_fake > 0 && n_real > 0, "gan_discr_loss_fwd: bad argument");
+  hipLaunchKernelGGL(gan_discr_loss_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits_fake, (int)n_fake, logits_real,
+                     (int)n_real, out1);
+  return mi355_check_launch("gan_discr_loss_fwd");
+}
+
+int mi355_gan_discr_loss_bwd(const float* logits_fake, int32_t n_fake, const float* logits_real, int32_t n_real,
+                             const float* upstream, float* dfake, float* dreal, void* stream) {
+  MI355_REQUIRE(logits_fake && logits_real && upstream && dfake && dreal && n_fake > 0 && n_real > 0, "gan_discr_loss_bwd: bad argument");
+  hipLaunchKernelGGL(gan_discr_loss_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits_fake, (int)n_fake, logits_real,
+                     (int)n_real, upstream, dfake, dreal);
+  return mi355_check_launch("gan_discr_loss_bwd");
 }
 
 int mi355_l1_bwd(const float* a, const float* b, int64_t count, const float* gscale, float* da, void* stream) {

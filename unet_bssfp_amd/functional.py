@@ -886,3 +886,60 @@ class L1LossFn(Function):
 
 def l1_loss(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return L1LossFn.apply(a, b)
+
+
+class GanGenLossFn(Function):
+    """The generator phase's loss head (src/model.py:126-137) as one launch each way on top of the L1 kernels:
+    (adv + recon, [L1, recon, adv, adv + recon]) with adv = BCEWithLogits(logits, 1).mean() and recon = L1(y_hat, y) / divisor
+    * factor.  In a graph replay a launch costs ~5 us whatever its size; the composed form is ~27 scalar-sized launches."""
+
+    @staticmethod
+    def forward(ctx, logits, y_hat, y, divisor: float, factor: float):
+        logits, y_hat, y = logits.contiguous(), y_hat.contiguous(), y.contiguous()
+        out = ops.gan_gen_loss_fwd(logits, y_hat, y, divisor, factor)
+        ctx.save_for_backward(logits, y_hat, y)
+        ctx.scale = (divisor, factor)
+        ctx.mark_non_differentiable(out)
+        return out[3], out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g, _):
+        logits, y_hat, y = ctx.saved_tensors
+        dlogits, gscale = ops.gan_gen_loss_bwd(logits, g, *ctx.scale)
+        dy_hat = ops.l1_bwd(y_hat, y, gscale) if ctx.needs_input_grad[1] else None
+        return dlogits if ctx.needs_input_grad[0] else None, dy_hat, None, None, None
+
+
+class GanDiscrLossFn(Function):
+    """The discriminator phase's loss (src/model.py:183-193): (BCEWithLogits(real, 1).mean() + BCEWithLogits(fake, 0).mean()) / 2
+    in one launch each way.  ``real`` None: ``fake`` holds both logit maps stacked along the batch, fake first
+    (Discriminator.forward_pair's single pass) -- the gradient is then one tensor, no slice / pad / add nodes."""
+
+    @staticmethod
+    def forward(ctx, fake, real):
+        stacked = real is None
+        fake = fake.contiguous()
+        if stacked:
+            half = fake.numel() // 2
+            flat = fake.view(-1)
+            f, r = flat[:half], flat[half:]
+        else:
+            real = real.contiguous()
+            f, r = fake, real
+        out = ops.gan_discr_loss_fwd(f, r)
+        ctx.save_for_backward(fake, real)
+        return out[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        fake, real = ctx.saved_tensors
+        if real is None:
+            d = torch.empty_like(fake)
+            half = fake.numel() // 2
+            ops.gan_discr_loss_bwd(fake.view(-1)[:half], fake.view(-1)[half:], g, d.view(-1)[:half], d.view(-1)[half:])
+            return d, None
+        df, dr = torch.empty_like(fake), torch.empty_like(real)
+        ops.gan_discr_loss_bwd(fake, real, g, df, dr)
+        return df, dr

@@ -112,9 +112,24 @@ class bSSFPToDWITensorModel(nn.Module):
         logs[f"{prefix}_loss_recon"] = total.detach()
         return total
 
+    fused_loss_heads = True             # HIP path: the loss heads as one launch each way (functional.GanGenLossFn / GanDiscrLossFn)
+
+    def _fused_losses(self, *tensors) -> bool:
+        """The default loss configuration on device f32 tensors: BCEWithLogits + L1 and their arithmetic as single launches
+        (same formulas; ~45 scalar-sized torch launches per step otherwise, ~5 us each in a graph replay)."""
+        return (self.fused_loss_heads and self.l1_fn is None and not self.extra_recon_terms
+                and all(t.is_cuda and t.dtype == torch.float32 for t in tensors))
+
     def _gen_step(self, x, y, logs, step_name="train"):
         y_hat = self.gen(x)
         logits = self.discr(x, y_hat)
+        if self._fused_losses(logits, y_hat, y):
+            from .functional import GanGenLossFn
+            total, parts = GanGenLossFn.apply(logits, y_hat, y, float(self.recon_divisor or 1), float(self.recon_factor))
+            logs[f"{step_name}_gen_loss_recon_L1"] = parts[0]
+            logs[f"{step_name}_gen_loss_recon"] = parts[1]
+            logs[f"{step_name}_gen_loss_adversarial"] = parts[2]
+            return total, y_hat
         adv = F.binary_cross_entropy_with_logits(logits, torch.ones_like(logits))
         recon = self.compute_recon_loss(y_hat, y, logs, step_name + "_gen")
         logs[f"{step_name}_gen_loss_adversarial"] = adv.detach()
@@ -128,10 +143,17 @@ class bSSFPToDWITensorModel(nn.Module):
     def _discr_step(self, x, y):
         y_hat = self.gen(x).detach()
         if self._discr_pair():
-            logits_hat, logits = self.discr.forward_pair(x, y_hat, y)
+            both = self.discr.forward_pair(x, y_hat, y, stacked=self._fused_losses(x, y))
+            if isinstance(both, torch.Tensor):                      # one pass over both inputs: fake first, then real
+                from .functional import GanDiscrLossFn
+                return GanDiscrLossFn.apply(both, None)
+            logits_hat, logits = both
         else:
             logits_hat = self.discr(x, y_hat)
             logits = self.discr(x, y)
+        if self._fused_losses(logits_hat, logits):
+            from .functional import GanDiscrLossFn
+            return GanDiscrLossFn.apply(logits_hat, logits)
         loss_hat = F.binary_cross_entropy_with_logits(logits_hat, torch.zeros_like(logits_hat))
         loss = F.binary_cross_entropy_with_logits(logits, torch.ones_like(logits))
         return (loss + loss_hat) / 2

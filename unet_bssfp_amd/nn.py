@@ -250,12 +250,14 @@ class Discriminator(_Mi355Module):
         z, _ = self.final.forward_act(h)
         return Fn.UnpackFn.apply(z, 1)
 
-    def forward_pair(self, x, y_a, y_b):
+    def forward_pair(self, x, y_a, y_b, stacked: bool = False):
         """(self(x, y_a), self(x, y_b)) in ONE pass over the two inputs stacked along the batch -- the discriminator phase
         calls the network on the fake and on the real batch back to back (src/model.py:184-186).  Every BatchNorm normalises
         each half with its own batch statistics and updates the running statistics in call order (first y_a, then y_b), so
         the results are those of the two separate calls; the weight gradients arrive as one sum over both halves.  Half the
-        launches of a phase whose kernels (32^3 x 64 ... 4^3 x 512) cannot fill the chip one call at a time."""
+        launches of a phase whose kernels (32^3 x 64 ... 4^3 x 512) cannot fill the chip one call at a time.
+        stacked=True: when the single pass is taken, return its (2N, 1, ...) logits as ONE tensor (y_a's first) instead of the
+        two halves, so that the loss can hand one gradient tensor back."""
         ops.require_cuda(x, y_a, y_b)
         n = x.shape[0]
         cin = x.shape[1] + y_a.shape[1]
@@ -276,7 +278,7 @@ class Discriminator(_Mi355Module):
                 Fn.StageBoundary.mark(h)
         z, _ = self.final.forward_act(h)
         logits = Fn.UnpackFn.apply(z, 1)
-        return logits[:n], logits[n:]
+        return logits if stacked else (logits[:n], logits[n:])
 
 
 # ------------------------------------------------------------------------------------------

@@ -660,6 +660,50 @@ def l1_bwd(a, b, gscale: torch.Tensor) -> torch.Tensor:
     return da
 
 
+def gan_gen_loss_fwd(logits: torch.Tensor, y_hat: torch.Tensor, y: torch.Tensor, divisor: float, factor: float) -> torch.Tensor:
+    """-> f32[4] = (L1(y_hat, y), L1 / divisor * factor, mean BCEWithLogits(logits, 1), their sum): src/model.py:126-137"""
+    require_cuda(logits, y_hat, y)
+    assert logits.dtype == y_hat.dtype == y.dtype == torch.float32 and logits.is_contiguous() and y_hat.is_contiguous() and y.is_contiguous()
+    assert y_hat.shape == y.shape
+    lib = _lib.load()
+    cnt = y_hat.numel()
+    nb = lib.mi355_l1_blocks(cnt)
+    partials = torch.empty((nb,), dtype=torch.float32, device=y.device)
+    out = torch.empty((4,), dtype=torch.float32, device=y.device)
+    _lib.check(lib.mi355_l1_partials(y_hat.data_ptr(), y.data_ptr(), cnt, partials.data_ptr(), _stream()), "l1_partials")
+    _lib.check(lib.mi355_gan_gen_loss_fwd(logits.data_ptr(), logits.numel(), partials.data_ptr(), nb, cnt, divisor, factor,
+                                          out.data_ptr(), _stream()), "gan_gen_loss_fwd")
+    return out
+
+
+def gan_gen_loss_bwd(logits: torch.Tensor, upstream: torch.Tensor, divisor: float, factor: float):
+    """-> (dlogits, the device scalar l1_bwd scales with)"""
+    require_cuda(logits, upstream)
+    up = upstream.to(torch.float32).reshape(1).contiguous()
+    dlogits = torch.empty_like(logits)
+    gscale = torch.empty((1,), dtype=torch.float32, device=logits.device)
+    _lib.check(_lib.load().mi355_gan_gen_loss_bwd(logits.data_ptr(), logits.numel(), up.data_ptr(), divisor, factor,
+                                                  dlogits.data_ptr(), gscale.data_ptr(), _stream()), "gan_gen_loss_bwd")
+    return dlogits, gscale
+
+
+def gan_discr_loss_fwd(fake: torch.Tensor, real: torch.Tensor) -> torch.Tensor:
+    """(mean BCEWithLogits(real, 1) + mean BCEWithLogits(fake, 0)) / 2 as f32[1]: src/model.py:183-193"""
+    require_cuda(fake, real)
+    assert fake.dtype == real.dtype == torch.float32 and fake.is_contiguous() and real.is_contiguous()
+    out = torch.empty((1,), dtype=torch.float32, device=fake.device)
+    _lib.check(_lib.load().mi355_gan_discr_loss_fwd(fake.data_ptr(), fake.numel(), real.data_ptr(), real.numel(), out.data_ptr(),
+                                                    _stream()), "gan_discr_loss_fwd")
+    return out
+
+
+def gan_discr_loss_bwd(fake: torch.Tensor, real: torch.Tensor, upstream: torch.Tensor, dfake: torch.Tensor, dreal: torch.Tensor):
+    require_cuda(fake, real, upstream, dfake, dreal)
+    up = upstream.to(torch.float32).reshape(1).contiguous()
+    _lib.check(_lib.load().mi355_gan_discr_loss_bwd(fake.data_ptr(), fake.numel(), real.data_ptr(), real.numel(), up.data_ptr(),
+                                                    dfake.data_ptr(), dreal.data_ptr(), _stream()), "gan_discr_loss_bwd")
+
+
 def mfma_selftest(device) -> Tuple[torch.Tensor, torch.Tensor]:
     a = torch.zeros(1024, dtype=torch.float32, device=device)
     b = torch.zeros(1024, dtype=torch.float32, device=device)
