@@ -84,6 +84,7 @@ def parse():
                     help="world size > 1: broadcast rank 0's BatchNorm running statistics before every k-th step "
                          "(DDP's broadcast_buffers=True, src/train.py:30; 0 = never)")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch (--gpus N without torch.distributed.run): rendezvous port (0 = pick a free one)")
+    ap.add_argument("--separate-colsum", action="store_true", help="developer A/B: transposed-conv bias gradients by a separate pass over the gradient instead of the producing launch's statistics; reported")
     ap.add_argument("--composed-losses", action="store_true", help="developer A/B: BCE / L1 loss heads as composed torch ops instead of the one-launch kernels; reported")
     ap.add_argument("--side-stream", action="store_true", help="developer A/B: weight gradients of the small layers on a second stream (measured slower); reported")
     ap.add_argument("--small-norm-elements", type=int, default=None,
@@ -413,6 +414,10 @@ def main():
         from unet_bssfp_amd import functional as _Fn
         _Fn.SideStream.allowed = True
         nondefault["side_stream"] = True
+    if a.separate_colsum:
+        from unet_bssfp_amd import functional as _Fn2
+        _Fn2.ColSumSide.enabled = False
+        nondefault["separate_colsum"] = True
     if a.small_norm_elements is not None:
         ops.SMALL_NORM_ELEMENTS = a.small_norm_elements
         nondefault["small_norm_elements"] = a.small_norm_elements

@@ -280,6 +280,11 @@ int mi355_colsum_finalize(const float* part, int32_t parts, int32_t c, float* ou
 /* the same into caller-owned gradient storage: first n_out channels, optional accumulation */
 int mi355_colsum_finalize_into(const float* part, int32_t parts, int32_t c, float* out, int32_t n_out, int32_t accumulate,
                                void* stream);
+/* the same for channels offset .. offset + n_out of the partial rows -- e.g. the statistics a data-gradient convolution launch
+ * emitted for ALL its output channels, of which the second source's are the bias gradient of the transposed convolution that
+ * produced that source (MONAI UpCat, src/model.py:22-28): no separate pass over the gradient */
+int mi355_colsum_finalize_from(const float* part, int32_t parts, int32_t c, int32_t offset, float* out, int32_t n_out,
+                               int32_t accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * MaxPool3d(kernel_size=2) -- MONAI BasicUNet `Down` (call site src/model.py:22-28).

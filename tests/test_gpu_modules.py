@@ -751,3 +751,41 @@ def test_training_step_with_fused_loss_heads_tracks_the_composed_form(hip):
         moved += int(close.sum())
         assert close.float().mean() > 0.98, float(close.float().mean())
     assert moved > 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_transposed_conv_bias_gradient_from_the_producing_launch(hip, dtype):
+    """The bias gradient of the transposed convolution under a skip concatenation (MONAI UpCat, src/model.py:22-28) is the
+    per-channel sum of the data gradient that the following convolution's backward writes for its second source; that
+    launch emits the sums through its fused-statistics epilogue (functional.ColSumSide) instead of a separate pass over
+    the gradient.  Against the separate pass: same tensor summed in another order (f32 partial sums, f64 combination)."""
+    import unet_bssfp_amd as M
+    from unet_bssfp_amd import functional as Fn
+    from unet_bssfp_amd.nn import UpCat
+    torch.manual_seed(5)
+    blk = M.set_compute_dtype(UpCat(64, 32, 32, 0.0).to(DEV).train(), dtype)
+    g = torch.Generator().manual_seed(6)
+    from tests.test_gpu_ops import to_act
+    x = to_act(torch.randn(1, 64, 8, 16, 32, generator=g), dtype)
+    xe = to_act(torch.randn(1, 32, 16, 32, 64, generator=g), dtype)
+    gy = to_act(torch.randn(1, 32, 16, 32, 64, generator=g), dtype)
+    grads = {}
+    for carried in (True, False):
+        Fn.ColSumSide.enabled = carried
+        try:
+            blk.zero_grad()
+            xin = x.clone().requires_grad_(True)
+            y = blk.forward_act(xin, xe)
+            y.backward(gy)
+            grads[carried] = {n: p.grad.detach().clone() for n, p in blk.named_parameters()}
+        finally:
+            Fn.ColSumSide.enabled = True
+    a, b = grads[True]["upsample.deconv.bias"], grads[False]["upsample.deconv.bias"]
+    assert not torch.equal(a, torch.zeros_like(a))
+    # bf16: the separate pass sums the bf16-ROUNDED gradient, the carried sums come from the f32 accumulators before rounding:
+    # they differ by the accumulated rounding noise, ~ sqrt(32768 voxels) * 2^-9 * rms (0.45 of a maximum of 61 measured)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert (a - b).abs().max() <= tol * b.abs().max() + 1e-6, ((a - b).abs().max(), b.abs().max())
+    for n in grads[True]:
+        if n != "upsample.deconv.bias":
+            assert torch.equal(grads[True][n], grads[False][n]), n

@@ -95,6 +95,7 @@ _SIGNATURES = {
     "mi355_normact_small_bwd": (C.c_int, [C.POINTER(NormSmallDesc), _vp]),
     "mi355_colsum_finalize": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "mi355_colsum_finalize_into": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "mi355_colsum_finalize_from": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "mi355_maxpool2_fwd": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mi355_maxpool2_bwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mi355_maxpool2_bwd_add": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -324,13 +324,14 @@ __global__ __launch_bounds__(1024) void norm_finalize_kernel(const float* __rest
   }
 }
 
-__global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ part, int parts, int c,
+// out[j] (+)= column sum of channel offset + j, j < n_out
+__global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ part, int parts, int c, int offset,
                                                                float* __restrict__ out, int n_out, int accumulate) {
-  const int ch0 = blockIdx.x * 8;
+  const int ch0 = offset + blockIdx.x * 8;
   double s0, s1;
   block_sum_parts(part, parts, c, ch0, s0, s1);
-  const int ch = ch0 + (int)threadIdx.x;
-  if (threadIdx.x < 8 && ch < n_out) out[ch] = accumulate ? out[ch] + (float)s0 : (float)s0;
+  const int j = blockIdx.x * 8 + (int)threadIdx.x;
+  if (threadIdx.x < 8 && j < n_out) out[j] = accumulate ? out[j] + (float)s0 : (float)s0;
 }
 
 // ------------------------------------------------------------------ norm + dropout + LeakyReLU
@@ -1424,8 +1425,14 @@ int mi355_colsum_finalize(const float* part, int32_t parts, int32_t c, float* ou
 
 int mi355_colsum_finalize_into(const float* part, int32_t parts, int32_t c, float* out, int32_t n_out, int32_t accumulate,
                                void* stream) {
-  MI355_REQUIRE(part && out && parts > 0 && c > 0 && n_out > 0 && n_out <= c, "colsum_finalize: bad argument");
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((c + 7) / 8), dim3(1024), 0, (hipStream_t)stream, part, parts, c, out, n_out, accumulate);
+  return mi355_colsum_finalize_from(part, parts, c, 0, out, n_out, accumulate, stream);
+}
+
+int mi355_colsum_finalize_from(const float* part, int32_t parts, int32_t c, int32_t offset, float* out, int32_t n_out,
+                               int32_t accumulate, void* stream) {
+  MI355_REQUIRE(part && out && parts > 0 && c > 0 && n_out > 0 && offset >= 0 && offset + n_out <= c, "colsum_finalize: bad argument");
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((n_out + 7) / 8), dim3(1024), 0, (hipStream_t)stream, part, parts, c, offset, out, n_out,
+                     accumulate);
   return mi355_check_launch("colsum_finalize");
 }
 

@@ -249,6 +249,27 @@ class Fp8Side:
         cls._by_ptr.clear()
 
 
+class ColSumSide:
+    """Per-channel sums of a data gradient, emitted by the convolution launch that PRODUCED it (fused statistics epilogue),
+    on their way to the node that needs them as a bias gradient (the transposed convolution under a skip concatenation:
+    its bias gradient was a separate pass over the full-resolution gradient).  Keyed like Fp8Side; emptied every step."""
+    _by_ptr = {}
+    enabled = True
+
+    @classmethod
+    def put(cls, t: torch.Tensor, part: torch.Tensor, offset: int):
+        cls._by_ptr[t.data_ptr()] = (part, offset, tuple(t.shape), t)
+
+    @classmethod
+    def take(cls, t: torch.Tensor):
+        hit = cls._by_ptr.pop(t.data_ptr(), None)
+        return (hit[0], hit[1]) if hit is not None and hit[2] == tuple(t.shape) else None
+
+    @classmethod
+    def clear(cls):
+        cls._by_ptr.clear()
+
+
 def fp8_operand(x: torch.Tensor, slot: "Fp8Scales.Slot", constant: bool = False) -> torch.Tensor:
     """The e4m3 copy of a convolution operand with the amax in ``slot.use``: the one its producer wrote if there is one;
     otherwise one cast pass with the previous step's amax (gathering this step's); on the slot's first step the in-step
@@ -561,6 +582,7 @@ class ConvFn(Function):
         x0, x1, weight = ctx.saved_tensors
         spec: ConvSpec = ctx.spec
         dz = ops.as_act(dz)
+        carried = ColSumSide.take(dz)           # per-channel sums of dz from the launch that produced it (bias gradient)
         n, di, hi, wi, c0 = x0.shape
         c1 = x1.shape[4] if x1 is not None else 0
         dtype, dev = x0.dtype, x0.device
@@ -571,6 +593,11 @@ class ConvFn(Function):
         need_dx = ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1])
         if need_dx:
             dxc = ops.new_act(n, di, hi, wi, c0 + c1, dtype, dev)
+            # the second source of a skip concatenation comes from a transposed convolution whose bias gradient is the
+            # per-channel sum of this data gradient: let the launch that writes it emit the sums (fused statistics)
+            sums = None
+            want_sums = (ColSumSide.enabled and x1 is not None and ctx.needs_input_grad[1] and spec.kind == "conv"
+                         and spec.stride == 1 and not ctx.s2d_cp)
             if ctx.s2d_cp:
                 wp, coutp, _ = spec.w_dgrad_s2d(weight, dtype, cg, ctx.s2d_cp)
                 ops.conv_fwd(dz, None, wp, coutp, None, 2, 1, (1, 1, 1), dxc, (di, hi, wi), real=(spec.cout, spec.cin))
@@ -578,12 +605,20 @@ class ConvFn(Function):
                   and ops.conv_fp8_supported(dz, round_up(c0 + c1, 32), dxc, (di, hi, wi))):
                 wp, coutp, _, amax_w = spec.w_dgrad8(weight, cg)
                 slot = spec.fp8_slot("g", dev)
-                ops.conv_fwd(fp8_operand(dz, slot), None, wp, coutp, None, 3, 1, (1, 1, 1), dxc, (di, hi, wi),
-                             real=(spec.cout, spec.cin), fp8=(slot.use, amax_w))
+                dz8, q = fp8_operand(dz, slot), (slot.use, amax_w)
+                if want_sums:
+                    tiles, _ = ops.conv_num_tiles(dz8, None, wp, coutp, 3, 1, (1, 1, 1), dxc, (di, hi, wi), fp8=q)
+                    sums = torch.empty((tiles, 2, coutp), dtype=torch.float32, device=dev)
+                ops.conv_fwd(dz8, None, wp, coutp, None, 3, 1, (1, 1, 1), dxc, (di, hi, wi),
+                             real=(spec.cout, spec.cin), fp8=q, stats=sums)
             elif spec.kind == "conv" and spec.stride == 1:
                 wp, coutp, _ = spec.w_dgrad_s1(weight, dtype, cg, c0 + c1)
-                ops.conv_fwd(dz, None, wp, coutp, None, k, 1, (k - 1 - spec.pad,) * 3, dxc, (di, hi, wi),
-                             real=(spec.cout, spec.cin))
+                pad3 = (k - 1 - spec.pad,) * 3
+                if want_sums:
+                    tiles, _ = ops.conv_num_tiles(dz, None, wp, coutp, k, 1, pad3, dxc, (di, hi, wi))
+                    sums = torch.empty((tiles, 2, coutp), dtype=torch.float32, device=dev)
+                ops.conv_fwd(dz, None, wp, coutp, None, k, 1, pad3, dxc, (di, hi, wi),
+                             real=(spec.cout, spec.cin), stats=sums)
             elif spec.kind == "conv":
                 if not (k == 4 and spec.stride == 2 and spec.pad == 1 and di % 2 == 0 and hi % 2 == 0 and wi % 2 == 0):
                     raise NotImplementedError("strided data gradient is implemented for k4 s2 p1 on even extents")
@@ -597,6 +632,8 @@ class ConvFn(Function):
                 ops.conv_fwd(dz, None, wp, coutp, None, 2, 2, (0, 0, 0), dxc, (di, hi, wi), real=(spec.cout, spec.cin))
             dx0 = dxc[..., :c0] if c1 else dxc
             dx1 = dxc[..., c0:] if c1 else None
+            if sums is not None:
+                ColSumSide.put(dx1, sums, c0)
         side = SideStream.enabled and n * do_ * ho * wo <= SideStream.max_rows
         if ctx.needs_input_grad[2]:
             # gradient storage owned by the path (gradsink.GradBuckets): the kernel writes (or, for a second use of the
@@ -640,11 +677,16 @@ class ConvFn(Function):
                     db = _cached_zeros(spec.cout, dev)
             elif bsink is not None:
                 fresh = bsink.fresh(ctx.bias_param)
-                if side:
+                if carried is not None:
+                    ops.colsum_from_parts(carried[0], carried[1], sink_grad(ctx.bias_param), accumulate=not fresh)
+                elif side:
                     SideStream.run(lambda: ops.colsum_into(dz, sink_grad(ctx.bias_param), accumulate=not fresh), dz)
                 else:
                     ops.colsum_into(dz, sink_grad(ctx.bias_param), accumulate=not fresh)
                 bsink.written(ctx.bias_param)
+            elif carried is not None:
+                db = torch.empty((spec.cout,), dtype=torch.float32, device=dev)
+                ops.colsum_from_parts(carried[0], carried[1], db)
             else:
                 db = ops.colsum(dz)[: spec.cout].contiguous()
         return dx0, dx1, dw, db, None, None, None, None, None
@@ -683,6 +725,7 @@ class DropoutState:
         cls.base(device).add_(1)
         cls._salt = 0
         PackMemo.clear()                    # a new training step: constant inputs are packed afresh
+        ColSumSide.clear()
         Fp8Scales.advance(device)           # ... and the e4m3 scales gathered in the last step come into use
 
     @classmethod

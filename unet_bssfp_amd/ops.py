@@ -438,6 +438,17 @@ def colsum_into(x: torch.Tensor, out: torch.Tensor, accumulate: bool):
                                                       1 if accumulate else 0, _stream()), "colsum_into")
 
 
+def colsum_from_parts(part: torch.Tensor, offset: int, out: torch.Tensor, accumulate: bool = False):
+    """out[j] (+)= sum over the rows of part[:, 0, offset + j]: per-channel sums from the fused statistics a convolution
+    launch emitted ([rows][2][C] partial {sum, sum of squares}), channels offset .. offset + out.numel()."""
+    require_cuda(part, out)
+    rows, two, c = part.shape
+    assert two == 2 and part.is_contiguous() and part.dtype == out.dtype == torch.float32 and out.is_contiguous()
+    assert 0 <= offset and offset + out.numel() <= c
+    _lib.check(_lib.load().mi355_colsum_finalize_from(part.data_ptr(), rows, c, offset, out.data_ptr(), out.numel(),
+                                                      1 if accumulate else 0, _stream()), "colsum_from_parts")
+
+
 def _normact_desc(z, groups, mean, rstd, gamma, beta, slope, drop_p, seed, seed_t=None):
     d = _lib.NormActDesc()
     n, dd, h, w, c = z.shape
