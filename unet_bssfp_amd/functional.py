@@ -237,6 +237,8 @@ class Fp8Side:
 
     @classmethod
     def put(cls, t: torch.Tensor, t8: torch.Tensor):
+        if len(cls._by_ptr) >= 32:          # (a loop that never starts a training step: nothing may pile up here)
+            cls._by_ptr.clear()
         cls._by_ptr[t.data_ptr()] = (t8, tuple(t.shape), t)
 
     @classmethod
@@ -258,6 +260,8 @@ class ColSumSide:
 
     @classmethod
     def put(cls, t: torch.Tensor, part: torch.Tensor, offset: int):
+        if len(cls._by_ptr) >= 32:
+            cls._by_ptr.clear()
         cls._by_ptr[t.data_ptr()] = (part, offset, tuple(t.shape), t)
 
     @classmethod
@@ -530,7 +534,8 @@ class ConvFn(Function):
             # BASELINE.json configs[4]: e4m3 operands (per-tensor scales) on the block-scaled MFMA, f32 accumulate, bf16 out
             wp, coutp, _, amax_w = spec.w_fwd8(weight, c0)
             slot = spec.fp8_slot("x", dev)
-            x8 = fp8_operand(x0, slot, constant=not x0.requires_grad and PackMemo.holds(x0))
+            # (the packed batch enters both generator passes of a training step: cast once; never memoised outside training)
+            x8 = fp8_operand(x0, slot, constant=torch.is_grad_enabled() and not x0.requires_grad and PackMemo.holds(x0))
             q = (slot.use, amax_w)
             bp = bias.detach() if bias is not None else None
             if want_stats:
