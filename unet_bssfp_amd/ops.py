@@ -553,7 +553,10 @@ def normact_bwd(z, da, groups, mean, rstd, gamma, beta, slope, drop_p, seed, bat
     return dz, dgamma, dbeta
 
 
-SMALL_NORM_ELEMENTS = 1 << 20      # tensors of up to 1 M elements (2 MB bf16) with >= 64 channels take the one-launch kernels
+# tensors of up to 512 K elements (1 MB bf16: 8^3 x 512, 16^3 x 128 ...) with >= 64 channels take the one-launch kernels.  Measured in
+# the full step (interleaved A/B, bench.py --small-norm-elements): 1 M (16^3 x 256 included) 12.42 ms, 600 K 12.21, 300 K 12.23,
+# never 12.33 -- one workgroup per 16 bytes of channels is too few workgroups for a 2 MB tensor
+SMALL_NORM_ELEMENTS = 1 << 19
 
 
 def norm_is_small(n: int, d: int, h: int, w: int, c: int) -> bool:
