@@ -39,10 +39,21 @@ int env_int(const char* name, int dflt) { const char* e = getenv(name); return e
 int forced_ct() { static const int v = env_int("MI355_CONV_CT", 0); return v; }
 int forced_ksplit() { static const int v = env_int("MI355_CONV_KSPLIT", 0); return v; }
 int forced_shape() { static const int v = env_int("MI355_CONV_SHAPE", -1); return v; }
+// planner constants (sweeps: tools/sweep_plan.sh)
+int tune_mg_minwg() { static const int v = env_int("MI355_MG_MINWG", 192); return v; }
+int tune_mg_fix() { static const int v = env_int("MI355_MG_FIX", 900); return v; }
+int tune_march_minwg() { static const int v = env_int("MI355_MARCH_MINWG", 128); return v; }
+int tune_ks_target() { static const int v = env_int("MI355_KS_TARGET", 1024); return v; }
+int tune_low_min() { static const int v = env_int("MI355_LOW_MIN", 512); return v; }
 #else
 constexpr int forced_ct() { return 0; }
 constexpr int forced_ksplit() { return 0; }
 constexpr int forced_shape() { return -1; }
+constexpr int tune_mg_minwg() { return 192; }
+constexpr int tune_mg_fix() { return 900; }
+constexpr int tune_march_minwg() { return 128; }
+constexpr int tune_ks_target() { return 1024; }
+constexpr int tune_low_min() { return 512; }
 #endif
 
 int make_plan(const mi355_conv_desc* d, Plan* p) {
@@ -115,7 +126,7 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
             if (best < 0 || cost < best) { best = cost; best_len = len; }
           }
           const int segs = ceil_div(d->do_, best_len);
-          if (fp * segs >= 128 || f == 10 || d->dtype == MI355_DT_FP8) {
+          if (fp * segs >= tune_march_minwg() || f == 10 || d->dtype == MI355_DT_FP8) {
             pick = 10;
             p->seg_len = best_len;
             p->nseg = segs;
@@ -135,8 +146,8 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
             const long long fp = (long long)d->n * ceil_div(d->ho, 4 * rows) * ceil_div(d->wo, 32) * (d->coutp / 32);
             for (int ns = 1; ns <= d->do_ && ns <= 64; ++ns) {
               const int len = ceil_div(d->do_, ns), segs = ceil_div(d->do_, len);
-              if (fp * segs < 192 && f != 11) continue;     // must fill (most of) the chip
-              const long long rounds = (fp * segs + 255) / 256, cost = rounds * ((len + 2) * 900ll + (long long)len * 1728 * rows);
+              if (fp * segs < tune_mg_minwg() && f != 11) continue;     // must fill (most of) the chip
+              const long long rounds = (fp * segs + 255) / 256, cost = rounds * ((len + 2) * (long long)tune_mg_fix() + (long long)len * 1728 * rows);
               if (best < 0 || cost < best) { best = cost; best_len = len; best_rows = rows; }
             }
             if (best >= 0) break;
@@ -158,8 +169,8 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
       if (p->shape == 0 && p->ct == 1 && d->ks == 3 && count(0, 1) <= 512) p->shape = 4;
     } else {
       // low levels: few tiles -> favour more, smaller workgroups (the K loop is long, the grid is not)
-      if (count(p->shape, p->ct) < 512) p->ct = 1;
-      if (count(p->shape, p->ct) < 512) p->shape += 3;
+      if (count(p->shape, p->ct) < tune_low_min()) p->ct = 1;
+      if (count(p->shape, p->ct) < tune_low_min()) p->shape += 3;
     }
     if (p->shape == 10) {
       p->vt = 4; p->ct = 1;
@@ -202,7 +213,7 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
     const int nchunks = (d->c0 + d->c1) / 16;
     const int fk = forced_ksplit();
     if ((fk == 0 && ((wgs < 256 && nchunks >= 8) || (wgs <= 512 && nchunks >= 16))) || fk > 1) {   // (32^3 x 128 ch measured slower split)
-      long long ks = (1024 + wgs - 1) / wgs;
+      long long ks = (tune_ks_target() + wgs - 1) / wgs;
       if (fk > 1) ks = fk;
       if (ks > nchunks / 2) ks = nchunks / 2;
       if (ks > 32) ks = 32;
