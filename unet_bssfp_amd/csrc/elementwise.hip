@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(256) void gan_discr_loss_bwd_kernel(const float* __
 // Tensor pointers travel BY VALUE in the kernel arguments (chunks of kAdamChunk tensors), so the
 // launch needs no device-side table and can be captured into a hipGraph; the step count is read
 // from device memory when given (a captured launch then advances with its counter).
-constexpr int kAdamChunk = 24;
+constexpr int kAdamChunk = 64;      // (2.5 KB of kernel arguments; 24 cost the generator 5 launches per update)
 struct AdamChunk {
   float* p[kAdamChunk]; const float* g[kAdamChunk]; float* m[kAdamChunk]; float* v[kAdamChunk];
   long long n[kAdamChunk];

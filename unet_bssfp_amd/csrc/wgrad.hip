@@ -762,6 +762,13 @@ struct WPlan { int ks, tpw, tap_groups, ci_tiles, co_tiles, splits, cinp32, cout
 
 const int kWTD[2] = {2, 2}, kWTH[2] = {4, 8}, kWTW[2] = {32, 16};
 
+// planner constant of the tile path as a diagnostic-build knob (tools/sweep_plan.sh)
+#ifdef MI355_DIAG
+int tune_wg_target() { static const int v = [] { const char* e = getenv("MI355_WG_TARGET"); return e ? atoi(e) : 512; }(); return v; }
+#else
+constexpr int tune_wg_target() { return 512; }
+#endif
+
 int wplan(const mi355_wgrad_desc* d, WPlan* p) {
   MI355_REQUIRE(d && d->x0 && d->g && d->dw, "wgrad: null pointer");
   MI355_REQUIRE(d->dtype == MI355_DT_F32 || d->dtype == MI355_DT_BF16, "wgrad: bad dtype");
@@ -809,7 +816,7 @@ int wplan(const mi355_wgrad_desc* d, WPlan* p) {
     // transposed conv at the wide levels: 4 column tiles per workgroup (wgrad_deconv_kernel)
     p->deconv4 = cls && p->shape == 0 && p->co_tiles % kDeconvNco == 0 && d->do_ % 2 == 0 && d->ho % 4 == 0 && d->wo % 32 == 0;
     const long long cot = p->deconv4 ? p->co_tiles / kDeconvNco : p->co_tiles;
-    long long sp = 512 / ((long long)p->ci_tiles * cot);      // ~2 workgroups per CU (256 measured slower)
+    long long sp = tune_wg_target() / ((long long)p->ci_tiles * cot);      // ~2 workgroups per CU (256, 1024 measured slower)
     if (sp < 1) sp = 1;
     if (sp > p->ntiles) sp = p->ntiles;
     while (sp > 1 && sp * wsl * slab_bytes > (256ll << 20)) sp /= 2;
