@@ -29,8 +29,9 @@ int gcd_i(long long a, long long b) { while (b) { long long t = a % b; a = b; b 
 // 10 march (16x32 footprint marching along d, 32 input channels resident: conv_march_kernel; tile extents set in make_plan)
 // 11 marchg (4 ROWS x 32 footprint marching along d, input channels in 32-channel groups, weights streamed through an LDS
 //    ring: conv_marchg_kernel<ROWS>; vt = ROWS)
-const int kTD[10] = {2, 2, 4, 4, 2, 2, 4, 8, 4, 4}, kTH[10] = {4, 8, 8, 4, 4, 8, 4, 4, 4, 4}, kTW[10] = {32, 16, 8, 32, 16, 8, 32, 32, 32, 32},
-          kVT[10] = {2, 2, 2, 4, 1, 1, 2, 4, 4, 4};
+// 12 / 13 lowg (512-voxel tiles 4x8x16 / 8x8x8 x 64 output channels, weights through LDS once per workgroup: conv_lowg_kernel)
+const int kTD[14] = {2, 2, 4, 4, 2, 2, 4, 8, 4, 4, 0, 0, 4, 8}, kTH[14] = {4, 8, 8, 4, 4, 8, 4, 4, 4, 4, 0, 0, 8, 8},
+          kTW[14] = {32, 16, 8, 32, 16, 8, 32, 32, 32, 32, 0, 0, 16, 8}, kVT[14] = {2, 2, 2, 4, 1, 1, 2, 4, 4, 4, 0, 0, 4, 4};
 
 // Plan overrides for A/B runs exist only in the diagnostic build (-DMI355_DIAG, built by tools/build_diag.sh into
 // tools/_build/, never shipped): MI355_CONV_SHAPE=<0|6|9|10>, MI355_CONV_CT=<1|2>, MI355_CONV_KSPLIT=<n>.
@@ -45,6 +46,9 @@ int tune_mg_fix() { static const int v = env_int("MI355_MG_FIX", 900); return v;
 int tune_march_minwg() { static const int v = env_int("MI355_MARCH_MINWG", 128); return v; }
 int tune_ks_target() { static const int v = env_int("MI355_KS_TARGET", 1024); return v; }
 int tune_low_min() { static const int v = env_int("MI355_LOW_MIN", 512); return v; }
+int tune_lowg() { static const int v = env_int("MI355_LOWG", 1); return v; }          // 0: the low levels stay on conv_halo_kernel
+int tune_lowg_target() { static const int v = env_int("MI355_LOWG_TARGET", 256); return v; }
+int tune_lowg_minch() { static const int v = env_int("MI355_LOWG_MINCH", 4); return v; }     // least 16-channel chunks
 #else
 constexpr int forced_ct() { return 0; }
 constexpr int forced_ksplit() { return 0; }
@@ -54,6 +58,9 @@ constexpr int tune_mg_fix() { return 900; }
 constexpr int tune_march_minwg() { return 128; }
 constexpr int tune_ks_target() { return 1024; }
 constexpr int tune_low_min() { return 512; }
+constexpr int tune_lowg() { return 1; }
+constexpr int tune_lowg_target() { return 256; }
+constexpr int tune_lowg_minch() { return 4; }
 #endif
 
 int make_plan(const mi355_conv_desc* d, Plan* p) {
@@ -167,6 +174,11 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
       // ... and when even that leaves <= 2 workgroups per CU, half-width tiles (2x4x16, one subtile per wave) double
       // them again: -0.1 ms per step in the interleaved A/B (256->128 at 32^3: 98 -> 91 us, 128->64: 31 -> 26 us)
       if (p->shape == 0 && p->ct == 1 && d->ks == 3 && count(0, 1) <= 512) p->shape = 4;
+    } else if (tune_lowg() && d->dtype == MI355_DT_BF16 && d->ks == 3 && d->coutp % 64 == 0 && (d->c0 + d->c1) >= 16 * tune_lowg_minch() &&
+               (long long)d->n * d->do_ * d->ho * d->wo >= 256) {
+      // low levels in bf16: 512-voxel tiles x 64 output channels, weights through LDS once per workgroup (conv_lowg_kernel)
+      p->shape = d->wo > 8 ? 12 : 13;
+      p->ct = 2;
     } else {
       // low levels: few tiles -> favour more, smaller workgroups (the K loop is long, the grid is not)
       if (count(p->shape, p->ct) < tune_low_min()) p->ct = 1;
@@ -212,10 +224,11 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
     const long long wgs = p->tiles * (d->coutp / (32 * p->ct));
     const int nchunks = (d->c0 + d->c1) / 16;
     const int fk = forced_ksplit();
-    if ((fk == 0 && ((wgs < 256 && nchunks >= 8) || (wgs <= 512 && nchunks >= 16))) || fk > 1) {   // (32^3 x 128 ch measured slower split)
-      long long ks = (tune_ks_target() + wgs - 1) / wgs;
+    const bool lowg = p->shape == 12 || p->shape == 13;       // one workgroup per CU: aim at 256 of them, down to one chunk each
+    if ((fk == 0 && (lowg ? wgs < tune_lowg_target() : ((wgs < 256 && nchunks >= 8) || (wgs <= 512 && nchunks >= 16)))) || fk > 1) {   // (32^3 x 128 ch measured slower split)
+      long long ks = lowg ? (tune_lowg_target() + wgs - 1) / wgs : (tune_ks_target() + wgs - 1) / wgs;
       if (fk > 1) ks = fk;
-      if (ks > nchunks / 2) ks = nchunks / 2;
+      if (ks > (lowg ? nchunks : nchunks / 2)) ks = lowg ? nchunks : nchunks / 2;
       if (ks > 32) ks = 32;
       if (ks >= 2) {
         p->ksplit = (int)ks;
@@ -315,6 +328,16 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
         if constexpr (sizeof(T) == 2) {
           if (p.ct == 2) conv_ru_kernel<2><<<grid, block, kRuLds, st>>>(a);
           else conv_ru_kernel<1><<<grid, block, kRuLds, st>>>(a);
+        }
+      } else if (p.shape == 12 || p.shape == 13) {
+        if constexpr (sizeof(T) == 2) {
+          static const int once = [] {
+            (void)hipFuncSetAttribute((const void*)conv_lowg_kernel<4, 8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, LowGCfg<4, 8, 16>::LDS);
+            return (int)hipFuncSetAttribute((const void*)conv_lowg_kernel<8, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LowGCfg<8, 8, 8>::LDS);
+          }();
+          (void)once;
+          if (p.shape == 12) conv_lowg_kernel<4, 8, 16><<<grid, block, LowGCfg<4, 8, 16>::LDS, st>>>(a);
+          else conv_lowg_kernel<8, 8, 8><<<grid, block, LowGCfg<8, 8, 8>::LDS, st>>>(a);
         }
       } else { HALO_KS(3) }
     } else { HALO_KS(2) }

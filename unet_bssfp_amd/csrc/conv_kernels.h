@@ -182,6 +182,248 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && CT == 2 && NW == 4) ? 3
   conv_epilogue_tile<T, VT, CT, TW, NW>(a, acc, to, co_base, tile, reinterpret_cast<float*>(smem));
 }
 
+// ------------------------------------------------------------------------------------------
+// conv_lowg_kernel: 3x3x3 stride-1 convolution (and data gradient) of the LOW levels in bf16 -- 16^3 / 8^3 of the U-Net
+// (src/model.py:22-28: down_3, down_4, upcat_4, upcat_3): 4 096 / 512 output positions, 128 ... 512 channels either side.
+// conv_halo_kernel ran these at 0.25 - 0.5 PFLOP/s whatever its tile or split: every WAVE fetched its own
+// weight fragments from L2, 27 KB per 16-channel chunk in three dependent groups, each fragment used once -- L2 latency,
+// not bandwidth, not the grid.  Here
+//   * a workgroup owns 512 output positions (TD x TH x TW, four 32-voxel sub-tiles per wave) x 64 output channels:
+//     a weight fragment feeds 4 MFMAs per wave, an activation fragment 2;
+//   * weights go through LDS ONCE per workgroup: block (chunk, kd) = 9 taps x 64 channels x 32 B in a 48-byte-pitch slot
+//     (conflict-free ds_read_b128: 16 lanes x 48 B cover the 16 bank groups), two slots; the copy for block b + 2 is in
+//     flight in registers (loaded during block b, stored to the free slot at the start of block b + 1) -- one block =
+//     72 MFMAs per wave = 2 304 cycles of cover for an L2 hit;
+//   * the halo of the next 16-channel chunk is prefetched into registers as in conv_halo_kernel.
+// Split-K over chunks (blockIdx.z) into the f32 slabs that conv_ksplit_reduce_kernel combines; one workgroup per CU
+// (107 KB of LDS), so the plan aims at 256 workgroups.
+// ------------------------------------------------------------------------------------------
+template <int TD, int TH, int TW>
+struct LowGCfg {
+  static constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, VS = 48;
+  static constexpr int HALO = HD * HH * HW * VS;
+  static constexpr int WROW = 48, WSLOT = 9 * 64 * WROW;
+  static constexpr int LDS = HALO + 2 * WSLOT;
+};
+
+template <int TD, int TH, int TW>
+__global__ __launch_bounds__(256, 1) void conv_lowg_kernel(const ConvArgs a) {
+  using T = bf16_t;
+  using Cfg = LowGCfg<TD, TH, TW>;
+  constexpr int CT = 2, NW = 4;
+  constexpr int RS = 32 / TW, SPD = TH / RS, NSUB = TD * SPD, VT = NSUB / NW;
+  static_assert(NSUB % NW == 0 && TW * RS == 32 && TH % RS == 0 && VT == 4, "tile shape");
+  constexpr int HH = Cfg::HH, HW = Cfg::HW, VS = Cfg::VS;
+  constexpr int NPIECE = Cfg::HD * HH * HW * 2, NP = (NPIECE + 255) / 256;      // 16-B pieces of a chunk's halo
+  constexpr int NWP = 9 * 64 * 2, NWI = (NWP + 255) / 256;                       // ... of a weight slot
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const wl = smem + Cfg::HALO;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int co_base = blockIdx.y * 64;
+  int tile;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;
+  }
+  int tn, d0, h0, w0;
+  {
+    int t = tile;
+    const int tw_i = t % a.tiles_w; t /= a.tiles_w;
+    const int th_i = t % a.tiles_h; t /= a.tiles_h;
+    const int td_i = t % a.tiles_d;
+    tn = t / a.tiles_d;
+    d0 = td_i * TD; h0 = th_i * TH; w0 = tw_i * TW;
+  }
+  // halo pieces of this thread: global voxel index (or -1) and LDS offset, chunk-invariant
+  int gvox[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int p = tid + i * 256, vox = p >> 1;
+    const int hd = vox / (HW * HH), hh = (vox / HW) % HH, hw = vox % HW;
+    const int gd = d0 + hd - a.pd, gh = h0 + hh - a.ph, gw = w0 + hw - a.pw;
+    const bool ok = p < NPIECE && gd >= 0 && gd < a.di && gh >= 0 && gh < a.hi && gw >= 0 && gw < a.wi;
+    gvox[i] = ok ? ((tn * a.di + gd) * a.hi + gh) * a.wi + gw : -1;
+  }
+  const int cps = (a.nchunks + a.ksplit - 1) / a.ksplit;
+  const int c_begin_of = blockIdx.z * cps;                 // split-K: this workgroup contracts chunks [c_begin_of, c_end)
+  const int c_end = min(a.nchunks, c_begin_of + cps);
+  uint4 stage[NP];
+#define LOWG_LOAD_CHUNK(C)                                                                                       \
+  {                                                                                                              \
+    const int cb_ = (C) * 16;                                                                                    \
+    const bool first_ = cb_ < a.c0;                                                                              \
+    const char* src_ = first_ ? a.x0 : a.x1;                                                                     \
+    const long long ld_ = first_ ? a.ld0 : a.ld1;                                                                \
+    const int cbase_ = first_ ? cb_ : cb_ - a.c0;                                                                \
+    _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                             \
+      const int part_ = (tid + i * 256) & 1;                                                                     \
+      if (gvox[i] >= 0) stage[i] = *reinterpret_cast<const uint4*>(src_ + ((long long)gvox[i] * ld_ + cbase_) * 2 + part_ * 16); \
+      else stage[i] = make_uint4(0, 0, 0, 0);                                                                    \
+    }                                                                                                            \
+  }
+#define LOWG_STORE_CHUNK()                                                                                       \
+  {                                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                             \
+      const int p_ = tid + i * 256;                                                                              \
+      if (p_ < NPIECE) *reinterpret_cast<uint4*>(smem + (p_ >> 1) * VS + (p_ & 1) * 16) = stage[i];              \
+    }                                                                                                            \
+  }
+  // weight slot of block (chunk c, kd): packed weights are [chunk][27 taps][coutp][16 channels].  TWO register sets: the
+  // copy of block b + 1 is stored to the free slot at the start of block b and its set re-used for block b + 3, while
+  // the other set holds block b + 2 -- every copy has two blocks (~4 600 cycles) of flight time, enough for a weight
+  // slice that comes from HBM (one workgroup per CU: nothing else hides that latency).
+  // (two plain arrays and macros: an array handed to a lambda by reference stayed in scratch memory -- a scratch store
+  //  right behind every global load, i.e. the full load latency exposed per block: 3.6 us per block instead of 1.1)
+  static_assert(NWI == 5, "five named registers per set below");
+  uint4 wa0, wa1, wa2, wa3, wa4, wb0, wb1, wb2, wb3, wb4;      // (named scalars: arrays of these ended up in scratch memory)
+  auto w_src = [&](int b, int i) __attribute__((always_inline)) {
+    const int c = c_begin_of + b / 3, kd = b - (b / 3) * 3;
+    const int p = min(tid + i * 256, NWP - 1);              // piece = (tap9, cout, half)
+    return reinterpret_cast<const uint4*>(a.wp + ((((long long)c * 27 + kd * 9 + (p >> 7)) * a.coutp + co_base + ((p >> 1) & 63)) * 32 + (p & 1) * 16));
+  };
+  auto w_dst = [&](int slot, int i) __attribute__((always_inline)) {
+    const int p = min(tid + i * 256, NWP - 1);              // (the clamped threads rewrite piece NWP - 1 with its own value)
+    return reinterpret_cast<uint4*>(wl + slot * Cfg::WSLOT + (p >> 1) * Cfg::WROW + (p & 1) * 16);
+  };
+#define LOWG_LOAD_W(W, B) { W##0 = *w_src(B, 0); W##1 = *w_src(B, 1); W##2 = *w_src(B, 2); W##3 = *w_src(B, 3); W##4 = *w_src(B, 4); }
+#define LOWG_STORE_W(W, SLOT) { *w_dst(SLOT, 0) = W##0; *w_dst(SLOT, 1) = W##1; *w_dst(SLOT, 2) = W##2; *w_dst(SLOT, 3) = W##3; *w_dst(SLOT, 4) = W##4; }
+
+  int lbase[VT];
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt) {
+    const int s = wave * VT + vt;
+    const int sd = s / SPD, sh = (s % SPD) * RS;
+    lbase[vt] = ((sd * HH + sh + r / TW) * HW + (r % TW)) * VS + h * 16;
+  }
+  const int wfrag = r * Cfg::WROW + h * 16;
+
+  f32x16 acc[VT][CT];
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[vt][ct][i] = 0.f;
+
+  const int nblk = (c_end - c_begin_of) * 3;
+  if (nblk > 0) {
+    LOWG_LOAD_CHUNK(c_begin_of)
+    LOWG_LOAD_W(wa, 0)
+    LOWG_LOAD_W(wb, 1)                                     // (nblk >= 3)
+    LOWG_STORE_W(wa, 0)                                    // block 0 -> slot 0
+    LOWG_LOAD_W(wa, 2)
+  }
+  // block b (parity P = b & 1): weights in slot P; wb / wa (P = 0 / 1) holds block b + 1, the other set block b + 2
+  auto block = [&](int b, auto par) __attribute__((always_inline)) {
+    constexpr int P = decltype(par)::value;
+    const int c = c_begin_of + b / 3, kd = b - (b / 3) * 3;
+    __syncthreads();               // block b - 1 is done everywhere: slot 1 - P (and, at kd == 0, the halo) is free
+    if (kd == 0) {
+      LOWG_STORE_CHUNK()
+      if (c + 1 < c_end) LOWG_LOAD_CHUNK(c + 1)             // in flight under this chunk's three blocks
+    }
+    if (b + 1 < nblk) {
+      if constexpr (P == 0) LOWG_STORE_W(wb, 1) else LOWG_STORE_W(wa, 0)
+    }
+    __syncthreads();               // halo and both slots visible
+    if (b + 3 < nblk) {
+      if constexpr (P == 0) LOWG_LOAD_W(wb, b + 3) else LOWG_LOAD_W(wa, b + 3)
+    }
+    const char* ws = wl + P * Cfg::WSLOT + wfrag;
+    const char* hs = smem + kd * HH * HW * VS;
+    // one wave per SIMD: nobody else hides the LDS latency, so the 6 fragment reads of tap t + 1 are issued between the 8
+    // MFMAs of tap t (two register sets, the order pinned: left to itself hipcc read each fragment right before its use)
+    uint4 f0a, f0b, f0c, f0d, f0e, f0f, f1a, f1b, f1c, f1d, f1e, f1f;
+#define LOWG_READ(S, T9)                                                                                         \
+  {                                                                                                              \
+    const int t_ = ((T9) / 3 * HW + (T9) % 3) * VS;                                                              \
+    S##a = *reinterpret_cast<const uint4*>(ws + ((T9) * 64) * Cfg::WROW);                                        \
+    S##b = *reinterpret_cast<const uint4*>(ws + ((T9) * 64 + 32) * Cfg::WROW);                                   \
+    S##c = *reinterpret_cast<const uint4*>(hs + lbase[0] + t_);                                                  \
+    S##d = *reinterpret_cast<const uint4*>(hs + lbase[1] + t_);                                                  \
+    S##e = *reinterpret_cast<const uint4*>(hs + lbase[2] + t_);                                                  \
+    S##f = *reinterpret_cast<const uint4*>(hs + lbase[3] + t_);                                                  \
+  }
+#define LOWG_MMA(S)                                                                                              \
+  {                                                                                                              \
+    Frag<T> b0_, b1_, a_;                                                                                        \
+    b0_.v = S##a; b1_.v = S##b;                                                                                  \
+    a_.v = S##c; mma16(a_, b0_, acc[0][0]); mma16(a_, b1_, acc[0][1]);                                           \
+    a_.v = S##d; mma16(a_, b0_, acc[1][0]); mma16(a_, b1_, acc[1][1]);                                           \
+    a_.v = S##e; mma16(a_, b0_, acc[2][0]); mma16(a_, b1_, acc[2][1]);                                           \
+    a_.v = S##f; mma16(a_, b0_, acc[3][0]); mma16(a_, b1_, acc[3][1]);                                           \
+  }
+#define LOWG_PIN()                                                                                               \
+  {                                                                                                              \
+    _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) {                                                           \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      /* one MFMA */                                     \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      /* one LDS read */                                 \
+    }                                                                                                            \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                           \
+  }
+#ifndef LOWG_DIAG_NO_MMA
+    LOWG_READ(f0, 0)
+    LOWG_READ(f1, 1) LOWG_MMA(f0) LOWG_PIN()
+    LOWG_READ(f0, 2) LOWG_MMA(f1) LOWG_PIN()
+    LOWG_READ(f1, 3) LOWG_MMA(f0) LOWG_PIN()
+    LOWG_READ(f0, 4) LOWG_MMA(f1) LOWG_PIN()
+    LOWG_READ(f1, 5) LOWG_MMA(f0) LOWG_PIN()
+    LOWG_READ(f0, 6) LOWG_MMA(f1) LOWG_PIN()
+    LOWG_READ(f1, 7) LOWG_MMA(f0) LOWG_PIN()
+    LOWG_READ(f0, 8) LOWG_MMA(f1) LOWG_PIN()
+    LOWG_MMA(f0)
+#endif
+#undef LOWG_READ
+#undef LOWG_MMA
+#undef LOWG_PIN
+  };
+  for (int b = 0; b < nblk; b += 2) {
+    block(b, std::integral_constant<int, 0>{});
+    if (b + 1 < nblk) block(b + 1, std::integral_constant<int, 1>{});
+  }
+#undef LOWG_LOAD_W
+#undef LOWG_LOAD_CHUNK
+#undef LOWG_STORE_CHUNK
+#undef LOWG_STORE_W
+
+  // ---- epilogue: as conv_halo_kernel ----
+#ifdef LOWG_DIAG_NO_STORE
+  if (acc[0][0][0] != 12345.678f) return;      // (timing-only build)
+#endif
+  TileOut<VT> to;
+  to.hstride = (long long)a.os * a.wy * a.ldy;
+  to.wstride = (long long)a.os * a.ldy;
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt) {
+    const int s = wave * VT + vt;
+    const int gd = d0 + s / SPD, gh = h0 + (s % SPD) * RS, gw = w0;
+    to.base[vt] = ((((long long)tn * a.dy + (gd * a.os + a.od)) * a.hy + (gh * a.os + a.oh)) * a.wy + (gw * a.os + a.ow)) * a.ldy;
+    to.dvalid[vt] = gd < a.do_;
+    to.hleft[vt] = a.ho - gh;
+    to.wleft[vt] = a.wo - gw;
+  }
+  if (a.ksplit > 1) {
+    ConvArgs s2 = a;
+    s2.y = reinterpret_cast<char*>(a.kslab + (long long)blockIdx.z * a.m_total * a.coutp);
+    s2.ldy = a.coutp; s2.cstore = a.coutp; s2.bias = nullptr; s2.stats = nullptr;
+    to.hstride = (long long)a.wo * a.coutp;
+    to.wstride = a.coutp;
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt) {
+      const int s = wave * VT + vt;
+      const int gd = d0 + s / SPD, gh = h0 + (s % SPD) * RS, gw = w0;
+      to.base[vt] = ((((long long)tn * a.do_ + gd) * a.ho + gh) * a.wo + gw) * a.coutp;
+    }
+    __syncthreads();                 // every wave is done with the halo and the slots: the epilogue reuses the LDS
+    conv_epilogue_tile<float, VT, CT, TW, NW>(s2, acc, to, co_base, tile, reinterpret_cast<float*>(smem));
+    return;
+  }
+  __syncthreads();
+  conv_epilogue_tile<T, VT, CT, TW, NW>(a, acc, to, co_base, tile, reinterpret_cast<float*>(smem));
+}
+
 // Combine the split-K slabs: z = sum_k slab[k] + bias, store in T at the (possibly scattered) output
 // position, and emit the per-block channel statistics of (z - bias).  One block = rpb positions.
 template <typename T>
