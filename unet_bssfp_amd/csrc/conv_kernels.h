@@ -203,7 +203,7 @@ struct LowGCfg {
   static constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, VS = 48;
   static constexpr int HALO = HD * HH * HW * VS;
   static constexpr int WROW = 48, WSLOT = 9 * 64 * WROW;
-  static constexpr int LDS = HALO + 2 * WSLOT;
+  static constexpr int LDS = 2 * HALO + 2 * WSLOT;            // two halo buffers, two weight slots: 158 976 B for 4x8x16
 };
 
 template <int TD, int TH, int TW>
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256, 1) void conv_lowg_kernel(const ConvArgs a) {
   constexpr int NPIECE = Cfg::HD * HH * HW * 2, NP = (NPIECE + 255) / 256;      // 16-B pieces of a chunk's halo
   constexpr int NWP = 9 * 64 * 2, NWI = (NWP + 255) / 256;                       // ... of a weight slot
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const wl = smem + Cfg::HALO;
+  char* const wl = smem + 2 * Cfg::HALO;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -240,10 +240,10 @@ __global__ __launch_bounds__(256, 1) void conv_lowg_kernel(const ConvArgs a) {
   int gvox[NP];
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
-    const int p = tid + i * 256, vox = p >> 1;
+    const int p = min(tid + i * 256, NPIECE - 1), vox = p >> 1;          // (threads beyond the last piece duplicate it)
     const int hd = vox / (HW * HH), hh = (vox / HW) % HH, hw = vox % HW;
     const int gd = d0 + hd - a.pd, gh = h0 + hh - a.ph, gw = w0 + hw - a.pw;
-    const bool ok = p < NPIECE && gd >= 0 && gd < a.di && gh >= 0 && gh < a.hi && gw >= 0 && gw < a.wi;
+    const bool ok = gd >= 0 && gd < a.di && gh >= 0 && gh < a.hi && gw >= 0 && gw < a.wi;
     gvox[i] = ok ? ((tn * a.di + gd) * a.hi + gh) * a.wi + gw : -1;
   }
   const int cps = (a.nchunks + a.ksplit - 1) / a.ksplit;
@@ -258,16 +258,24 @@ __global__ __launch_bounds__(256, 1) void conv_lowg_kernel(const ConvArgs a) {
     const long long ld_ = first_ ? a.ld0 : a.ld1;                                                                \
     const int cbase_ = first_ ? cb_ : cb_ - a.c0;                                                                \
     _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                             \
-      const int part_ = (tid + i * 256) & 1;                                                                     \
+      const int part_ = min(tid + i * 256, NPIECE - 1) & 1;                                                      \
       if (gvox[i] >= 0) stage[i] = *reinterpret_cast<const uint4*>(src_ + ((long long)gvox[i] * ld_ + cbase_) * 2 + part_ * 16); \
       else stage[i] = make_uint4(0, 0, 0, 0);                                                                    \
     }                                                                                                            \
   }
-#define LOWG_STORE_CHUNK()                                                                                       \
+#define LOWG_STORE_CHUNK_PART(HB, K3) /* a third of the staged chunk's pieces */                                 \
+  {                                                                                                              \
+    constexpr int n3_ = (NP + 2) / 3, lo_ = (K3) * n3_, hi_ = lo_ + n3_ < NP ? lo_ + n3_ : NP;                   \
+    _Pragma("unroll") for (int i = lo_; i < hi_; ++i) {                                                          \
+      const int p_ = min(tid + i * 256, NPIECE - 1);   /* (clamped threads rewrite the last piece with its own value) */ \
+      *reinterpret_cast<uint4*>(smem + (HB) * Cfg::HALO + (p_ >> 1) * VS + (p_ & 1) * 16) = stage[i];            \
+    }                                                                                                            \
+  }
+#define LOWG_STORE_CHUNK(HB)                                                                                     \
   {                                                                                                              \
     _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                             \
       const int p_ = tid + i * 256;                                                                              \
-      if (p_ < NPIECE) *reinterpret_cast<uint4*>(smem + (p_ >> 1) * VS + (p_ & 1) * 16) = stage[i];              \
+      if (p_ < NPIECE) *reinterpret_cast<uint4*>(smem + (HB) * Cfg::HALO + (p_ >> 1) * VS + (p_ & 1) * 16) = stage[i]; \
     }                                                                                                            \
   }
   // weight slot of block (chunk c, kd): packed weights are [chunk][27 taps][coutp][16 channels].  TWO register sets: the
@@ -313,26 +321,24 @@ __global__ __launch_bounds__(256, 1) void conv_lowg_kernel(const ConvArgs a) {
     LOWG_LOAD_W(wa, 0)
     LOWG_LOAD_W(wb, 1)                                     // (nblk >= 3)
     LOWG_STORE_W(wa, 0)                                    // block 0 -> slot 0
+    LOWG_STORE_CHUNK(0)                                    // chunk 0 -> halo buffer 0
     LOWG_LOAD_W(wa, 2)
+    if (c_begin_of + 1 < c_end) LOWG_LOAD_CHUNK(c_begin_of + 1)
   }
-  // block b (parity P = b & 1): weights in slot P; wb / wa (P = 0 / 1) holds block b + 1, the other set block b + 2
-  auto block = [&](int b, auto par) __attribute__((always_inline)) {
-    constexpr int P = decltype(par)::value;
-    const int c = c_begin_of + b / 3, kd = b - (b / 3) * 3;
-    __syncthreads();               // block b - 1 is done everywhere: slot 1 - P (and, at kd == 0, the halo) is free
-    if (kd == 0) {
-      LOWG_STORE_CHUNK()
-      if (c + 1 < c_end) LOWG_LOAD_CHUNK(c + 1)             // in flight under this chunk's three blocks
-    }
-    if (b + 1 < nblk) {
-      if constexpr (P == 0) LOWG_STORE_W(wb, 1) else LOWG_STORE_W(wa, 0)
-    }
-    __syncthreads();               // halo and both slots visible
-    if (b + 3 < nblk) {
-      if constexpr (P == 0) LOWG_LOAD_W(wb, b + 3) else LOWG_LOAD_W(wa, b + 3)
-    }
+  // Block b = 6 q + B6: weight slot P = B6 & 1, kd = B6 % 3, halo buffer HB = (B6 / 3) & 1 -- all compile-time.  ONE barrier
+  // per block, at its start: it publishes what block b - 1 wrote (slot P; a third of the halo buffer) and frees what block
+  // b - 1 read (slot 1 - P; after a chunk's last block its halo buffer).  During block b the wave writes block b + 1's
+  // weights into slot 1 - P and a third of the NEXT chunk's halo into the other buffer -- unconditional LDS writes pinned
+  // between the MFMAs (timing-only builds of the two-barrier form: copy phases and MFMAs did not overlap at all, 2.2 + 3.3 us
+  // per chunk); the global loads that refill the registers follow the MFMA stream.  wb / wa (P = 0 / 1) holds block
+  // b + 1, the other set block b + 2; `stage` holds the next chunk.  Writes of a block that does not exist land in free
+  // buffers.
+  auto block = [&](int b, auto b6) __attribute__((always_inline)) {
+    constexpr int B6 = decltype(b6)::value, P = B6 & 1, kd = B6 % 3, HB = (B6 / 3) & 1;
+    const int c = c_begin_of + b / 3;
+    __syncthreads();
     const char* ws = wl + P * Cfg::WSLOT + wfrag;
-    const char* hs = smem + kd * HH * HW * VS;
+    const char* hs = smem + HB * Cfg::HALO + kd * HH * HW * VS;
     // one wave per SIMD: nobody else hides the LDS latency, so the 6 fragment reads of tap t + 1 are issued between the 8
     // MFMAs of tap t (two register sets, the order pinned: left to itself hipcc read each fragment right before its use)
     uint4 f0a, f0b, f0c, f0d, f0e, f0f, f1a, f1b, f1c, f1d, f1e, f1f;
@@ -361,28 +367,57 @@ __global__ __launch_bounds__(256, 1) void conv_lowg_kernel(const ConvArgs a) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      /* one MFMA */                                     \
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      /* one LDS read */                                 \
     }                                                                                                            \
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                           \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                           \
+    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);        /* one LDS write (next block's weights / next halo) */ \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                           \
+  }
+  // one LDS write per tap, in program order BETWEEN the reads of tap t + 1 and those of tap t + 2 (hipcc keeps LDS writes
+  // and reads in program order: it cannot know that they touch different buffers)
+#define LOWG_WW(I) { if constexpr (P == 0) *w_dst(1, I) = wb##I; else *w_dst(0, I) = wa##I; }
+#define LOWG_WS(J)                                                                                               \
+  {                                                                                                              \
+    constexpr int n3_ = (NP + 2) / 3, i_ = kd * n3_ + (J);                                                       \
+    if constexpr ((J) < n3_ && i_ < NP) {                                                                        \
+      const int p_ = min(tid + i_ * 256, NPIECE - 1);   /* (clamped threads rewrite the last piece with its own value) */ \
+      *reinterpret_cast<uint4*>(smem + (1 - HB) * Cfg::HALO + (p_ >> 1) * VS + (p_ & 1) * 16) = stage[i_];       \
+    }                                                                                                            \
   }
 #ifndef LOWG_DIAG_NO_MMA
     LOWG_READ(f0, 0)
-    LOWG_READ(f1, 1) LOWG_MMA(f0) LOWG_PIN()
-    LOWG_READ(f0, 2) LOWG_MMA(f1) LOWG_PIN()
-    LOWG_READ(f1, 3) LOWG_MMA(f0) LOWG_PIN()
-    LOWG_READ(f0, 4) LOWG_MMA(f1) LOWG_PIN()
-    LOWG_READ(f1, 5) LOWG_MMA(f0) LOWG_PIN()
-    LOWG_READ(f0, 6) LOWG_MMA(f1) LOWG_PIN()
-    LOWG_READ(f1, 7) LOWG_MMA(f0) LOWG_PIN()
-    LOWG_READ(f0, 8) LOWG_MMA(f1) LOWG_PIN()
+    LOWG_READ(f1, 1) LOWG_WW(0) LOWG_MMA(f0) LOWG_PIN()
+    LOWG_READ(f0, 2) LOWG_WW(1) LOWG_MMA(f1) LOWG_PIN()
+    LOWG_READ(f1, 3) LOWG_WW(2) LOWG_MMA(f0) LOWG_PIN()
+    LOWG_READ(f0, 4) LOWG_WW(3) LOWG_MMA(f1) LOWG_PIN()
+    LOWG_READ(f1, 5) LOWG_WW(4) LOWG_MMA(f0) LOWG_PIN()
+    LOWG_READ(f0, 6) LOWG_WS(0) LOWG_MMA(f1) LOWG_PIN()
+    LOWG_READ(f1, 7) LOWG_WS(1) LOWG_MMA(f0) LOWG_PIN()
+    LOWG_READ(f0, 8) LOWG_WS(2) LOWG_MMA(f1) LOWG_PIN()
     LOWG_MMA(f0)
+#else
+    LOWG_WW(0) LOWG_WW(1) LOWG_WW(2) LOWG_WW(3) LOWG_WW(4) LOWG_WS(0) LOWG_WS(1) LOWG_WS(2)
 #endif
+#undef LOWG_WW
+#undef LOWG_WS
 #undef LOWG_READ
 #undef LOWG_MMA
 #undef LOWG_PIN
+    // refill the registers that were just stored (the copies have one to two blocks of flight time)
+    if (b + 3 < nblk) {
+      if constexpr (P == 0) LOWG_LOAD_W(wb, b + 3) else LOWG_LOAD_W(wa, b + 3)
+    }
+    if (kd == 2 && c + 2 < c_end) LOWG_LOAD_CHUNK(c + 2)
   };
-  for (int b = 0; b < nblk; b += 2) {
+  for (int b = 0; b < nblk; b += 6) {
     block(b, std::integral_constant<int, 0>{});
-    if (b + 1 < nblk) block(b + 1, std::integral_constant<int, 1>{});
+    block(b + 1, std::integral_constant<int, 1>{});
+    block(b + 2, std::integral_constant<int, 2>{});
+    if (b + 3 < nblk) {
+      block(b + 3, std::integral_constant<int, 3>{});
+      block(b + 4, std::integral_constant<int, 4>{});
+      block(b + 5, std::integral_constant<int, 5>{});
+    }
   }
+#undef LOWG_STORE_CHUNK_PART
 #undef LOWG_LOAD_W
 #undef LOWG_LOAD_CHUNK
 #undef LOWG_STORE_CHUNK
