@@ -49,6 +49,7 @@ int tune_low_min() { static const int v = env_int("MI355_LOW_MIN", 512); return 
 int tune_lowg() { static const int v = env_int("MI355_LOWG", 1); return v; }          // 0: the low levels stay on conv_halo_kernel
 int tune_lowg_target() { static const int v = env_int("MI355_LOWG_TARGET", 256); return v; }
 int tune_lowg_minch() { static const int v = env_int("MI355_LOWG_MINCH", 4); return v; }     // least 16-channel chunks
+int tune_lowg_maxw() { static const int v = env_int("MI355_LOWG_MAXW", 16); return v; }      // widest row the low-level plans take
 #else
 constexpr int forced_ct() { return 0; }
 constexpr int forced_ksplit() { return 0; }
@@ -61,6 +62,7 @@ constexpr int tune_low_min() { return 512; }
 constexpr int tune_lowg() { return 1; }
 constexpr int tune_lowg_target() { return 256; }
 constexpr int tune_lowg_minch() { return 4; }
+constexpr int tune_lowg_maxw() { return 16; }
 #endif
 
 int make_plan(const mi355_conv_desc* d, Plan* p) {
@@ -94,7 +96,11 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
   p->halo = ((d->ks == 3 || d->ks == 2) && d->stride == 1);
   if (p->halo) {
     if (forced_ct() == 1) p->ct = 1;
-    p->shape = d->wo > 16 ? 0 : (d->wo > 8 ? 1 : 2);
+    // low levels in bf16: 512-voxel tiles x 64 output channels, weights through LDS once per workgroup (conv_lowg_kernel)
+    const bool lowg_ok = tune_lowg() && d->dtype == MI355_DT_BF16 && d->ks == 3 && d->coutp % 64 == 0 &&
+                         (d->c0 + d->c1) >= 16 * tune_lowg_minch() && (long long)d->n * d->do_ * d->ho * d->wo >= 256 &&
+                         d->wo <= tune_lowg_maxw();
+    p->shape = (d->wo > 16 && !lowg_ok) ? 0 : (d->wo > 8 ? 1 : 2);       // (0: the wide-level plans below)
     auto count = [&](int sh, int ct) {
       return (long long)ceil_div(d->do_, kTD[sh]) * ceil_div(d->ho, kTH[sh]) * ceil_div(d->wo, kTW[sh]) * d->n *
              (d->coutp / (32 * ct));
@@ -174,9 +180,7 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
       // ... and when even that leaves <= 2 workgroups per CU, half-width tiles (2x4x16, one subtile per wave) double
       // them again: -0.1 ms per step in the interleaved A/B (256->128 at 32^3: 98 -> 91 us, 128->64: 31 -> 26 us)
       if (p->shape == 0 && p->ct == 1 && d->ks == 3 && count(0, 1) <= 512) p->shape = 4;
-    } else if (tune_lowg() && d->dtype == MI355_DT_BF16 && d->ks == 3 && d->coutp % 64 == 0 && (d->c0 + d->c1) >= 16 * tune_lowg_minch() &&
-               (long long)d->n * d->do_ * d->ho * d->wo >= 256) {
-      // low levels in bf16: 512-voxel tiles x 64 output channels, weights through LDS once per workgroup (conv_lowg_kernel)
+    } else if (lowg_ok) {
       p->shape = d->wo > 8 ? 12 : 13;
       p->ct = 2;
     } else {
