@@ -3,7 +3,7 @@ import csv, glob, sys, collections
 fs = glob.glob(sys.argv[1] + '/**/*kernel_stats.csv', recursive=True)
 n = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 rows = list(csv.DictReader(open(fs[0])))
-cats = collections.OrderedDict([("conv fwd/dgrad", ("conv_halo", "conv_gather", "conv_ksplit", "conv_ru", "conv_march", "conv_marchg", "pointwise_conv", "deconv_fwd")), ("weight grad", ("wgrad_",)),
+cats = collections.OrderedDict([("conv fwd/dgrad", ("conv_halo", "conv_gather", "conv_ksplit", "conv_ru", "conv_march", "conv_marchg", "conv_lowg", "pointwise_conv", "deconv_fwd")), ("weight grad", ("wgrad_",)),
         ("norm+act", ("normact", "norm_finalize", "channel_stats", "colsum", "amax_", "cast_fp8")), ("layout", ("pack_kernel", "pack_tile_kernel", "unpack_kernel", "wpack")),
         ("pool/loss/adam", ("maxpool", "l1_", "adamw", "gan_gen_loss", "gan_discr_loss")), ("torch native", ("at::native", "rocclr", "Memset", "Cijk")), ])
 tot = collections.Counter(); cnt = collections.Counter()
