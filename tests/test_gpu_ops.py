@@ -250,7 +250,8 @@ def test_conv_fwd_bwd(hip, case, dtype):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cin,cout,sp", [(64, 64, (2, 4, 8)), (128, 64, (4, 4, 4)),
                                          (64, 64, (64, 64, 33)), (128, 64, (32, 64, 65)),    # >= 131072 voxels: deconv_fwd_kernel in bf16
-                                         (64, 64, (8, 8, 32)), (128, 64, (4, 8, 64))])       # W % 32 == 0: wgrad_deconv_kernel in bf16
+                                         (64, 64, (8, 8, 32)), (128, 64, (4, 8, 64)),        # W % 32 == 0: wgrad_deconv_kernel in bf16
+                                         (256, 128, (8, 8, 8))])       # upcat_4's shape class: the data gradient's (tap, chunk) pairs split over blockIdx.z
 def test_deconv_fwd_bwd(hip, dtype, cin, cout, sp):
     from unet_bssfp_amd.nn import ConvTranspose3d
     g = torch.Generator().manual_seed(5)

@@ -50,6 +50,7 @@ int tune_lowg() { static const int v = env_int("MI355_LOWG", 1); return v; }    
 int tune_lowg_target() { static const int v = env_int("MI355_LOWG_TARGET", 256); return v; }
 int tune_lowg_minch() { static const int v = env_int("MI355_LOWG_MINCH", 4); return v; }     // least 16-channel chunks
 int tune_lowg_maxw() { static const int v = env_int("MI355_LOWG_MAXW", 16); return v; }      // widest row the low-level plans take
+int tune_gather_split() { static const int v = env_int("MI355_GATHER_SPLIT", 1); return v; }
 #else
 constexpr int forced_ct() { return 0; }
 constexpr int forced_ksplit() { return 0; }
@@ -63,6 +64,7 @@ constexpr int tune_lowg() { return 1; }
 constexpr int tune_lowg_target() { return 256; }
 constexpr int tune_lowg_minch() { return 4; }
 constexpr int tune_lowg_maxw() { return 16; }
+constexpr int tune_gather_split() { return 1; }
 #endif
 
 int make_plan(const mi355_conv_desc* d, Plan* p) {
@@ -221,6 +223,29 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
   MI355_REQUIRE(p->tiles < (1ll << 31), "conv: too many tiles");
   p->ksplit = 1; p->rpb = 0;
   p->stat_rows = p->tiles; p->stat_rows_per_sample = p->tiles_per_sample;
+  auto set_split = [&](long long ks) {
+    p->ksplit = (int)ks;
+    const long long per = (long long)d->do_ * d->ho * d->wo;
+    // rows per reduce block: divides the per-sample position count (statistics groups) and leaves >= ~512 blocks
+    const long long cblocks = (d->coutp + 1023) / 1024;
+    int rpb = 64;
+    while (rpb > 1 && (per % rpb != 0 || (per / rpb) * d->n * cblocks < 512)) rpb >>= 1;
+    p->rpb = gcd_i(per, rpb);
+    p->stat_rows_per_sample = (int)(per / p->rpb);
+    p->stat_rows = (long long)p->stat_rows_per_sample * d->n;
+  };
+  if (!p->halo && !d->cls_cout && d->os == 1 && d->ooff[0] == 0 && d->ooff[1] == 0 && d->ooff[2] == 0 && tune_gather_split()) {
+    // gather kernel with few output positions and a long contraction (the transposed convolutions' data gradients at the
+    // 16^3 / 8^3 levels: 128 dependent (tap, chunk) steps in 32 workgroups, 64 us for 1 GFLOP): split the (tap, chunk) pairs
+    const long long wgs = p->tiles * (d->coutp / (32 * p->ct));
+    const long long nit = (long long)d->ks * d->ks * d->ks * ((d->c0 + d->c1) / 16);
+    if (wgs < 128 && nit >= 32) {
+      long long ks = (256 + wgs - 1) / wgs;
+      if (ks > nit / 8) ks = nit / 8;
+      if (ks > 32) ks = 32;
+      if (ks >= 2) set_split(ks);
+    }
+  }
   if (p->halo && p->shape != 10 && p->shape != 11) {      // (the marching kernels walk the whole contraction themselves)
     // few output positions and a long contraction (8^3 / 16^3 U-Net levels, low PatchGAN levels): the
     // grid cannot fill 256 CUs and every workgroup streams its weights at one L2/HBM latency per tap
@@ -234,17 +259,7 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
       if (fk > 1) ks = fk;
       if (ks > (lowg ? nchunks : nchunks / 2)) ks = lowg ? nchunks : nchunks / 2;
       if (ks > 32) ks = 32;
-      if (ks >= 2) {
-        p->ksplit = (int)ks;
-        const long long per = (long long)d->do_ * d->ho * d->wo;
-        // rows per reduce block: divides the per-sample position count (statistics groups) and leaves >= ~512 blocks
-        const long long cblocks = (d->coutp + 1023) / 1024;
-        int rpb = 64;
-        while (rpb > 1 && (per % rpb != 0 || (per / rpb) * d->n * cblocks < 512)) rpb >>= 1;
-        p->rpb = gcd_i(per, rpb);
-        p->stat_rows_per_sample = (int)(per / p->rpb);
-        p->stat_rows = (long long)p->stat_rows_per_sample * d->n;
-      }
+      if (ks >= 2) set_split(ks);
     }
   }
   return MI355_OK;

@@ -570,8 +570,12 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[vt][ct][i] = 0.f;
 
-  int kd = 0, kh = 0, kw = 0;
-  for (int tap = 0; tap < ntaps; ++tap) {
+  // split-K (few output positions, long contraction -- the transposed convolutions' data gradients at the low levels ran
+  // 128 dependent (tap, chunk) steps in 32 workgroups): blockIdx.z takes a contiguous range of the (tap, chunk) pairs
+  const int nit = ntaps * a.nchunks, ipz = (nit + a.ksplit - 1) / a.ksplit;
+  const int it0 = blockIdx.z * ipz, it1 = min(nit, it0 + ipz);
+  for (int tap = it0 / a.nchunks; tap < ntaps && tap * a.nchunks < it1; ++tap) {
+    const int kd = tap / (a.ks * a.ks), kh = (tap / a.ks) % a.ks, kw = tap % a.ks;
     long long vox[VT];
 #pragma unroll
     for (int vt = 0; vt < VT; ++vt) {
@@ -581,7 +585,8 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvArgs a) {
       const bool ok = vok[vt] && id >= 0 && id < a.di && ih >= 0 && ih < a.hi && iw >= 0 && iw < a.wi;
       vox[vt] = ok ? (((long long)vn[vt] * a.di + id) * a.hi + ih) * a.wi + iw : -1;
     }
-    for (int c = 0; c < a.nchunks; ++c) {
+    const int cb0 = max(0, it0 - tap * a.nchunks), cb1 = min(a.nchunks, it1 - tap * a.nchunks);
+    for (int c = cb0; c < cb1; ++c) {
       const int cb = c * 16;
       const bool first = cb < a.c0;
       const char* src = first ? a.x0 : a.x1;
@@ -600,7 +605,20 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvArgs a) {
         for (int ct = 0; ct < CT; ++ct) mma16(af, b[ct], acc[vt][ct]);
       }
     }
-    if (++kw == a.ks) { kw = 0; if (++kh == a.ks) { kh = 0; ++kd; } }
+  }
+  if (a.ksplit > 1) {
+    // partial sums to the f32 slab of this split; bias, statistics and the store in T: conv_ksplit_reduce_kernel
+    ConvArgs s2 = a;
+    s2.y = reinterpret_cast<char*>(a.kslab + (long long)blockIdx.z * a.m_total * a.coutp);
+    s2.ldy = a.coutp; s2.cstore = a.coutp; s2.bias = nullptr; s2.stats = nullptr;
+    long long soff[VT];
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt) {
+      const long long m = (long long)blockIdx.x * (128 * VT) + (wave * VT + vt) * 32 + r;
+      soff[vt] = vok[vt] ? m * a.coutp : -1;
+    }
+    conv_epilogue<float, VT, CT>(s2, acc, soff, co_base, blockIdx.x, red, co_base, nullptr);
+    return;
   }
 
   // transposed-conv classes folded into the cout index: this workgroup's 32*CT columns belong to ONE class
