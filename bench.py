@@ -87,6 +87,7 @@ def parse():
     ap.add_argument("--separate-colsum", action="store_true", help="developer A/B: transposed-conv bias gradients by a separate pass over the gradient instead of the producing launch's statistics; reported")
     ap.add_argument("--composed-losses", action="store_true", help="developer A/B: BCE / L1 loss heads as composed torch ops instead of the one-launch kernels; reported")
     ap.add_argument("--side-stream", action="store_true", help="developer A/B: weight gradients of the small layers on a second stream (measured slower); reported")
+    ap.add_argument("--small-norm-grouped", type=int, default=None, help="developer A/B: the same limit for BatchNorm tensors whose statistic groups one workgroup walks in order (forward_pair)")
     ap.add_argument("--small-norm-elements", type=int, default=None,
                     help="developer A/B: size limit of the one-launch norm kernels (0 = off); reported")
     ap.add_argument("--lib", default=None, help="developer A/B: another build of the C ABI (tools/diaglib.py); reported")
@@ -421,6 +422,9 @@ def main():
     if a.small_norm_elements is not None:
         ops.SMALL_NORM_ELEMENTS = a.small_norm_elements
         nondefault["small_norm_elements"] = a.small_norm_elements
+    if a.small_norm_grouped is not None:
+        ops.SMALL_NORM_ELEMENTS_GROUPED = a.small_norm_grouped
+        nondefault["small_norm_grouped"] = a.small_norm_grouped
     dtype = M.compute_dtype_from_name(a.dtype)
     torch.manual_seed(0)                                   # identical init on every rank
     gen = M.Generator("bssfp", dropout=a.dropout)

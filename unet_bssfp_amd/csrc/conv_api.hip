@@ -239,7 +239,7 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
     // 16^3 / 8^3 levels: 128 dependent (tap, chunk) steps in 32 workgroups, 64 us for 1 GFLOP): split the (tap, chunk) pairs
     const long long wgs = p->tiles * (d->coutp / (32 * p->ct));
     const long long nit = (long long)d->ks * d->ks * d->ks * ((d->c0 + d->c1) / 16);
-    if (wgs < 128 && nit >= 32) {
+    if (wgs <= 128 && nit >= 32) {
       long long ks = (256 + wgs - 1) / wgs;
       if (ks > nit / 8) ks = nit / 8;
       if (ks > 32) ks = 32;

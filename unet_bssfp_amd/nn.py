@@ -195,7 +195,7 @@ class DownSampleConv(_Mi355Module):
         n, di, hi, wi = x0.shape[:4]
         ext = (di - 1, hi - 1, wi - 1) if s2d_cp else tuple(self.conv.spec.out_extent(e) for e in (di, hi, wi))
         # small outputs (the last PatchGAN blocks): the norm kernel computes the statistics itself, in one launch
-        small = fuse and ops.norm_is_small(n, *ext, round_up(self.conv.out_channels, 16))
+        small = fuse and ops.norm_is_small(n, *ext, round_up(self.conv.out_channels, 16), bn_groups)
         z, part = self.conv.forward_act(x0, x1, want_stats=fuse and not small, zero_bias_grad=fuse, s2d_cp=s2d_cp)
         if not (self.batchnorm or self.activation):
             assert not s2d_out

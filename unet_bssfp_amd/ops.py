@@ -559,9 +559,13 @@ def normact_bwd(z, da, groups, mean, rstd, gamma, beta, slope, drop_p, seed, bat
 SMALL_NORM_ELEMENTS = 1 << 19
 
 
-def norm_is_small(n: int, d: int, h: int, w: int, c: int) -> bool:
+SMALL_NORM_ELEMENTS_GROUPED = SMALL_NORM_ELEMENTS      # BatchNorm over several statistic groups walked in order by one workgroup
+
+
+def norm_is_small(n: int, d: int, h: int, w: int, c: int, serial_groups: int = 1) -> bool:
     """Does a (n, d, h, w, c) activation take the fused small-tensor norm kernels (mi355_normact_small_fwd / _bwd)?"""
-    return c >= 64 and n * d * h * w * c <= SMALL_NORM_ELEMENTS
+    limit = SMALL_NORM_ELEMENTS if serial_groups <= 1 else SMALL_NORM_ELEMENTS_GROUPED
+    return c >= 64 and n * d * h * w * c <= limit
 
 
 def normact_small_fwd(z, groups, gamma, beta, eps, slope, drop_p=0.0, seed=0, seed_t=None, running_mean=None,
