@@ -132,6 +132,7 @@ CONV_CASES = [
     ("k1_pointwise_head", 1, (24,), 24, (64, 64, 32), 1, 1, 0),
     ("k1_pointwise_final", 2, (32,), 6, (32, 64, 32), 1, 1, 0),
     ("k1_pointwise_ragged", 1, (16,), 32, (64, 64, 33), 1, 1, 0),
+    ("k1_pointwise_wgstats", 1, (24,), 24, (95, 96, 65), 1, 1, 0),   # > 2048 tiles, one sample: one statistics row per workgroup
 ]
 
 

@@ -16,6 +16,7 @@ struct Plan {
   int seg_len, nseg;          // marching kernel (shape 10): output planes per workgroup segment, segments per sample
   int ksplit, rpb;            // split-K factor (1 = off) and rows per reduce block
   long long stat_rows;        // rows of stats_part ( = tiles, or reduce blocks under split-K )
+  bool pointwise, wg_stats;   // persistent 1x1x1 kernel; its statistics as one row per workgroup
   int stat_rows_per_sample;
 };
 
@@ -223,6 +224,11 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
   MI355_REQUIRE(p->tiles < (1ll << 31), "conv: too many tiles");
   p->ksplit = 1; p->rpb = 0;
   p->stat_rows = p->tiles; p->stat_rows_per_sample = p->tiles_per_sample;
+  p->pointwise = !p->halo && d->dtype == MI355_DT_BF16 && !d->cls_cout && d->ks == 1 && d->stride == 1 && d->os == 1 && p->vt == 2 &&
+                 (d->c0 + d->c1) / 16 <= 2 && d->c1 == 0 && d->coutp == 32 && d->ooff[0] == 0 && d->ooff[1] == 0 && d->ooff[2] == 0 &&
+                 d->dy == d->do_ && d->hy == d->ho && d->wy == d->wo && d->pad[0] == 0 && d->pad[1] == 0 && d->pad[2] == 0;
+  p->wg_stats = p->pointwise && d->n == 1 && p->tiles > 2048;       // one statistics row per (persistent) workgroup
+  if (p->wg_stats) { p->stat_rows = 2048; p->stat_rows_per_sample = 2048; }
   auto set_split = [&](long long ks) {
     p->ksplit = (int)ks;
     const long long per = (long long)d->do_ * d->ho * d->wo;
@@ -360,14 +366,12 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
         }
       } else { HALO_KS(3) }
     } else { HALO_KS(2) }
-  } else if (sizeof(T) == 2 && !d->cls_cout && d->ks == 1 && d->stride == 1 && d->os == 1 && p.vt == 2 && a.nchunks <= 2 && d->c1 == 0 &&
-             d->coutp == 32 && d->ooff[0] == 0 && d->ooff[1] == 0 && d->ooff[2] == 0 && d->dy == d->do_ && d->hy == d->ho && d->wy == d->wo &&
-             d->pad[0] == 0 && d->pad[1] == 0 && d->pad[2] == 0) {
+  } else if (sizeof(T) == 2 && p.pointwise) {
     // full-resolution 1x1x1 convs with <= 32 channels either side: persistent streaming kernel
     const int ntiles = (int)p.tiles;
     const dim3 g1((unsigned)(ntiles < 2048 ? ntiles : 2048));
-    if (a.nchunks == 1) pointwise_conv_kernel<1><<<g1, block, 0, st>>>(a, ntiles);
-    else pointwise_conv_kernel<2><<<g1, block, 0, st>>>(a, ntiles);
+    if (a.nchunks == 1) pointwise_conv_kernel<1><<<g1, block, 0, st>>>(a, ntiles, p.wg_stats ? 1 : 0);
+    else pointwise_conv_kernel<2><<<g1, block, 0, st>>>(a, ntiles, p.wg_stats ? 1 : 0);
   } else if (sizeof(T) == 2 && d->cls_cout && p.vt == 2 && a.nchunks <= 8 && d->c1 == 0 && (d->cstore & 7) == 0) {
     // transposed-conv forward, Cin <= 128: one workgroup per 256 voxels loops over all column blocks
     const dim3 g1((unsigned)p.tiles);

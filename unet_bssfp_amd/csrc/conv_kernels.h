@@ -874,8 +874,11 @@ __global__ __launch_bounds__(256) void deconv_fwd_kernel(const ConvArgs a) {
 // tiles: the weight fragments stay in registers for the whole kernel and the next tile's A fragments are in
 // flight while the current tile's MFMAs and stores run.
 // ------------------------------------------------------------------------------------------
+// wg_stats: ONE statistics row per workgroup (all its tiles summed in registers) instead of one per tile: at 128^3 the
+// 8 192 per-tile rows made the following norm_finalize a 22 us launch (5 us for the rows of any other layer).  Only for
+// one sample: a workgroup's tiles stride over the whole tensor, per-sample rows could not be kept apart.
 template <int NCH>   // 16-channel chunks of the input (1 or 2)
-__global__ __launch_bounds__(256) void pointwise_conv_kernel(const ConvArgs a, int ntiles) {
+__global__ __launch_bounds__(256) void pointwise_conv_kernel(const ConvArgs a, int ntiles, int wg_stats) {
   using T = bf16_t;
   constexpr int VT = 2, CT = 1;
   __shared__ float red[4 * CT * 64];
@@ -900,6 +903,9 @@ __global__ __launch_bounds__(256) void pointwise_conv_kernel(const ConvArgs a, i
   };
   Frag<T> cur[VT][NCH], nxt[VT][NCH];
   long long mc[VT], mn[VT];
+  float ws1 = 0.f, ws2 = 0.f;                               // this lane's column (channel r), rows of its lane half
+  ConvArgs an = a;
+  if (wg_stats) an.stats = nullptr;
   int tile = blockIdx.x;
   if (tile < ntiles) load_tile(tile, cur, mc);
   for (; tile < ntiles; tile += gridDim.x) {
@@ -916,12 +922,40 @@ __global__ __launch_bounds__(256) void pointwise_conv_kernel(const ConvArgs a, i
     long long yoff[VT];
 #pragma unroll
     for (int vt = 0; vt < VT; ++vt) yoff[vt] = mc[vt] >= 0 ? mc[vt] * a.ldy : -1;
-    conv_epilogue<T, VT, CT>(a, acc, yoff, 0, tile, red, 0, tpatch);
+    if (wg_stats && a.stats) {
+#pragma unroll
+      for (int vt = 0; vt < VT; ++vt) {
+        const long long m0 = (long long)tile * (128 * VT) + (wave * VT + vt) * 32;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float v = (m0 + acc_row(i, h) < a.m_total) ? acc[vt][0][i] : 0.f;
+          ws1 += v;
+          ws2 += v * v;
+        }
+      }
+    }
+    conv_epilogue<T, VT, CT>(an, acc, yoff, 0, tile, red, 0, tpatch);
 #pragma unroll
     for (int vt = 0; vt < VT; ++vt) {
       mc[vt] = mn[vt];
 #pragma unroll
       for (int c = 0; c < NCH; ++c) cur[vt][c] = nxt[vt][c];
+    }
+  }
+  if (wg_stats && a.stats) {
+    // lane halves, then the 4 waves in a fixed order (deterministic), as conv_epilogue does per tile
+    ws1 += __shfl_xor(ws1, 32, 64);
+    ws2 += __shfl_xor(ws2, 32, 64);
+    __syncthreads();
+    if (h == 0) { red[(wave * 2 + 0) * 32 + r] = ws1; red[(wave * 2 + 1) * 32 + r] = ws2; }
+    __syncthreads();
+    if (wave == 0 && h == 0) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { t1 += red[(w * 2 + 0) * 32 + r]; t2 += red[(w * 2 + 1) * 32 + r]; }
+      float* p = a.stats + ((long long)blockIdx.x * 2) * a.coutp;
+      p[r] = t1;
+      p[a.coutp + r] = t2;
     }
   }
 }
