@@ -62,6 +62,27 @@ def bench_conv(dtype, reps, only=None):
         print(f"conv fwd  {name:28s} {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TFLOP/s   plan {plan[0]}  stat rows {tiles}")
 
 
+def bench_patchgan(dtype, reps, only=None):
+    """PatchGAN k4 s2 p1 blocks as dense k2 s1 convolutions on space-to-depth tensors (forward)"""
+    for name, cin, cout, s in [("d1 30->32 @128^3->64^3", 30, 32, 64), ("d2 32->64 @64^3->32^3", 32, 64, 32), ("d3 64->128 @32^3->16^3", 64, 128, 16)]:
+        if only and only not in name:
+            continue
+        layer = Conv3d(cin, cout, 4, 2, 1).to(DEV)
+        cp = ops.round_up(cin, 16)
+        x0 = torch.randn(1, s + 1, s + 1, s + 1, 8 * cp, device=DEV).to(dtype)
+        wp, coutp, _ = layer.spec.w_fwd_s2d(layer.weight, dtype, cp)
+        out = ops.new_act(1, s, s, s, ops.round_up(cout, 16), dtype, DEV)
+        bias = layer.bias.detach()
+        plan = []
+        ops.CONV_PROBE = lambda pid, d, real: plan.append(pid) and None
+        ops.conv_fwd(x0, None, wp, coutp, bias, 2, 1, (0, 0, 0), out, (s, s, s))
+        ops.CONV_PROBE = None
+        ms = timeit(lambda: ops.conv_fwd(x0, None, wp, coutp, bias, 2, 1, (0, 0, 0), out, (s, s, s)), reps)
+        fl = 2.0 * 8 * cp * 8 * cout * s ** 3
+        nb = x0.numel() * 2 + out.numel() * 2
+        print(f"conv k2/s2d {name:26s} {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TFLOP/s (dense)  {nb/ms/1e6:7.1f} GB/s  plan {plan[0]}")
+
+
 def bench_deconv(dtype, reps, only=None):
     """transposed conv k2 s2 (forward = one 1x1x1 GEMM with 8*Cout columns, data gradient = k2 s2 gather)"""
     from unet_bssfp_amd.nn import ConvTranspose3d
@@ -147,6 +168,8 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     if a.what in ("conv", "all"):
         bench_conv(dt, a.reps, a.only)
+    if a.what in ("patchgan", "all"):
+        bench_patchgan(dt, a.reps, a.only)
     if a.what in ("deconv", "all"):
         bench_deconv(dt, a.reps, a.only)
     if a.what in ("wgrad", "all"):
