@@ -1,3 +1,5 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): tools/gpu_final.sh -- the full -m gpu suite, then the round artefacts (tools/gpu_artifacts.sh r03)
 mkdir -p gpurun_out
 timeout -k 10 1000 python -m pytest tests -m gpu -q -x > gpurun_out/r03_pytest.log 2>&1; rc=$?
 echo "pytest rc=$rc"; tail -4 gpurun_out/r03_pytest.log
