@@ -42,7 +42,8 @@ def test_library_version_and_error_string_without_gpu():
     assert b"null" in lib.mi355_last_error()
     assert lib.mi355_l1_blocks(4096 * 3 + 1) == 4
     assert lib.mi355_channel_stats_blocks(2 ** 21) == 1024
-    assert lib.mi355_channel_stats_blocks(32 ** 3) == 256 and lib.mi355_channel_stats_blocks(100) == 1
+    assert lib.mi355_channel_stats_blocks(32 ** 3) == 256 and lib.mi355_channel_stats_blocks(100) == 6
+    assert lib.mi355_channel_stats_blocks(16 ** 3) == 256 and lib.mi355_channel_stats_blocks(8) == 1     # >= min(256, rows / 16) workgroups
 
 
 def test_missing_library_fails_loudly(monkeypatch):
