@@ -394,7 +394,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(a.backend)
-    nondefault = {k: v for k, v in os.environ.items() if k.startswith("MI355_") and k != "MI355_HOST_CORES"}
+    # MI355_* plan knobs are read by DIAGNOSTIC builds only (tools/build_diag.sh: -DMI355_DIAG); the shipped library ignores
+    # them, so they are recorded as non-default settings only when such a build is loaded (--lib)
+    nondefault = ({k: v for k, v in os.environ.items() if k.startswith("MI355_") and k != "MI355_HOST_CORES"} if a.lib else {})
     if a.backend != "nccl":
         nondefault["backend"] = a.backend
     if a.force_collectives:

@@ -34,7 +34,10 @@ def _worker(rank, world, port, mode, q):
         torch.manual_seed(10 + rank)                       # ranks start different: rank 0 is broadcast
         gen, discr = M.Generator("bssfp", dropout=0.0), M.Discriminator("bssfp")
         model = bSSFPToDWITensorModel("bssfp", gen=gen.to(dev), discr=discr.to(dev)).train()
-        batch = synthetic_batch(2, 32, seed=70 + rank, device=dev)
+        size = 48 if mode.startswith("eager48") else 32
+        batch = synthetic_batch(2, size, seed=70 + rank, device=dev)
+        if mode == "eager48_nopair":
+            model.pair_discriminator_calls = False
         extra = None
         if mode == "graph":
             ddp.broadcast_module_state(model.gen, 0)
@@ -65,6 +68,11 @@ def _worker(rank, world, port, mode, q):
             for i in range(3):
                 model.generator_only_step(batch, i)
             extra = list(model.sinks_gen.launch_order)
+        elif mode.startswith("eager48"):
+            ddp.attach(model)
+            for i in range(2):
+                model.training_step(batch, i)
+            extra = [model.sinks_discr.uses]
         else:
             ddp.attach(model)
             for i in range(4):
@@ -149,3 +157,14 @@ def test_zero_grad_on_sink_parameters_fails_loudly(hip):
     model.optimizers()[0].zero_grad()
     with pytest.raises(RuntimeError, match="gradient bucket"):
         model.generator_only_step(batch, 1)
+
+
+def test_discriminator_phase_as_two_calls_announces_two_contributions_two_ranks(hip):
+    """at extents that are not multiples of 32 (48^3) ``Discriminator.forward_pair`` falls back to two calls, so
+    every discriminator parameter receives TWO gradient contributions in the phase; the eagerly attached buckets must be
+    told so (an all-reduce launched after the first call's contributions would miss the second call's).  The default path
+    must equal the explicitly unpaired one bit for bit, on every rank."""
+    a, b = _run("eager48"), _run("eager48_nopair")
+    assert all(r[1] == "ok" for r in a + b), [r[1] for r in a + b]
+    assert all(r[3] == [2] for r in a + b), [r[3] for r in a + b]
+    assert a[0][2] == b[0][2]

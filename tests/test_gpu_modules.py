@@ -544,12 +544,13 @@ def test_hipgraph_two_input_sets_equal_eager_steps_on_alternating_batches(hip):
     # the eager model runs first and is snapshotted: build() resets the process-wide dropout counter, which a model that is
     # still stepping must not lose
     eager = build()
-    snaps = []
+    snaps, elogs = [], []
     for i, batch in enumerate((a, a, a, b, a, b, c)):         # two warm-up steps on A (as the graphed model), then A B A B, then C
         eager.training_step(batch, i)
         if i in (5, 6):
             torch.cuda.synchronize()
             snaps.append([p.detach().clone() for p in eager.parameters()])
+            elogs.append({k: float(v) for k, v in eager.last_logs.items()})
     graphed = build()
     gs = GraphedTrainingStep(graphed, a, warmup=2)
     assert gs.add_instance(b) == 1
@@ -558,6 +559,10 @@ def test_hipgraph_two_input_sets_equal_eager_steps_on_alternating_batches(hip):
     torch.cuda.synchronize()
     for (n, q), p in zip(graphed.named_parameters(), snaps[0]):
         assert torch.equal(p, q), n
+    # every instance logs into its own tensors (the second capture used to overwrite the first one's dict entries):
+    # after a replay of instance 1 last_logs holds the losses of THAT step (batch B), after instance 0 those of its step
+    assert gs.instances[0][2] is not gs.instances[1][2] and graphed.last_logs is gs.instances[1][2]
+    assert {k: float(v) for k, v in graphed.last_logs.items()} == elogs[0]
     # new data written into an input set between replays is what the next replay of that set trains on
     for key in ("bssfp", "dwi-tensor_orig"):
         a[key]["data"].copy_(c[key]["data"])
@@ -565,6 +570,46 @@ def test_hipgraph_two_input_sets_equal_eager_steps_on_alternating_batches(hip):
     torch.cuda.synchronize()
     for (n, q), p in zip(graphed.named_parameters(), snaps[1]):
         assert torch.equal(p, q), n
+    assert graphed.last_logs is gs.instances[0][2]
+    assert {k: float(v) for k, v in graphed.last_logs.items()} == elogs[1]
+
+
+def test_discriminator_forward_pair_in_eval_mode_equals_two_calls_and_the_oracle(hip):
+    """on a model in .eval() BatchNorm normalises with its running statistics -- ONE (1, c) mean / rstd row whatever
+    the stacked pass's bn_groups says (the kernel read mean[g * c + ch] for g = 1: out of bounds).  forward_pair in eval mode
+    == two calls (same kernels, same statistics) == the oracle's Discriminator in eval mode within the f32 bound;
+    the running statistics are loaded with non-trivial values so that a wrong row cannot hide behind mean 0 / var 1."""
+    import unet_bssfp_amd as M
+    from oracle import unet_ref as R
+    torch.manual_seed(4)
+    d = M.Discriminator("bssfp")
+    g = torch.Generator().manual_seed(6)
+    sd = d.state_dict()
+    for k, v in sd.items():
+        if k.endswith("running_mean"):
+            sd[k] = torch.randn(v.shape, generator=g) * 0.1
+        elif k.endswith("running_var"):
+            sd[k] = torch.rand(v.shape, generator=g) + 0.5
+    d.load_state_dict(sd)
+    ref = R.RefDiscriminator("bssfp")
+    ref.load_state_dict(sd)
+    ref.eval()
+    x = torch.rand(2, 24, 64, 64, 64, generator=g)
+    ya = torch.rand(2, 6, 64, 64, 64, generator=g)
+    yb = torch.rand(2, 6, 64, 64, 64, generator=g)
+    d = d.to(DEV).eval()
+    with torch.no_grad():
+        la, lb = d.forward_pair(x.to(DEV), ya.to(DEV), yb.to(DEV))
+        ta, tb = d(x.to(DEV), ya.to(DEV)), d(x.to(DEV), yb.to(DEV))
+        ra, rb = ref(x, ya), ref(x, yb)
+    torch.cuda.synchronize()
+    # (same kernels per sample; the split-K plan of the low levels may differ between 4 and 2 stacked samples: summation order)
+    torch.testing.assert_close(la, ta, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(lb, tb, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(la.cpu(), ra, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(lb.cpu(), rb, rtol=1e-3, atol=1e-4)
+    for k, v in d.state_dict().items():                       # eval mode: no buffer moves
+        assert torch.equal(v.cpu(), sd[k]), k
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -789,3 +834,42 @@ def test_transposed_conv_bias_gradient_from_the_producing_launch(hip, dtype):
     for n in grads[True]:
         if n != "upsample.deconv.bias":
             assert torch.equal(grads[True][n], grads[False][n]), n
+
+
+def test_gan_step_at_the_reference_batch_8x64_matches_oracle(hip):
+    """The reference's REAL training shape (src/data_module.py:12, 18, 185-188): 8 patches of 64^3 per step -- the same voxel
+    count as one 128^3 volume, but every BatchNorm (generator head, PatchGAN) sees N = 8 and the discriminator phase stacks
+    16 samples through ``forward_pair``.  f32 parity mode against the CPU oracle: generator output per-voxel L1 <= 1e-4
+    (north_star's bound) and the step-0 losses within rtol 1e-3 (the discriminator loss, which already sees the generator's
+    first AdamW update: 2e-3, the bound of smoke())."""
+    import unet_bssfp_amd as M
+    from oracle import unet_ref as R
+    from unet_bssfp_amd.gan import bSSFPToDWITensorModel, synthetic_batch
+    torch.manual_seed(21)
+    gen, discr = M.Generator("bssfp", dropout=0.0), M.Discriminator("bssfp")
+    rgen, rdiscr = R.RefGenerator("bssfp", dropout=0.0).train(), R.RefDiscriminator("bssfp").train()
+    rgen.load_state_dict(gen.state_dict())
+    rdiscr.load_state_dict(discr.state_dict())
+    x, y = R.synthetic_batch(8, 64, seed=4321)
+    batch = synthetic_batch(8, 64, seed=4321, device=DEV)
+    assert torch.equal(batch["bssfp"]["data"].cpu(), x)
+    gen, discr = gen.to(DEV).train(), discr.to(DEV).train()
+    with torch.no_grad():                      # (train mode on both sides: the head's BatchNorm uses the statistics of the 8 patches)
+        y_hip = gen(batch["bssfp"]["data"]).cpu()
+        y_ref = rgen(x)
+    err = float((y_hip - y_ref).abs().mean())
+    assert err <= 1e-4, err
+    model = bSSFPToDWITensorModel("bssfp", gen=gen, discr=discr).train()
+    assert model._discr_uses(batch["bssfp"]["data"], batch["dwi-tensor_orig"]["data"]) == 1      # the stacked pass is what runs
+    model.training_step(batch, 0)
+    torch.cuda.synchronize()
+    g_opt, d_opt = R.make_optimizers(rgen, rdiscr)
+    ref = R.gan_training_step(rgen, rdiscr, g_opt, d_opt, x, y)
+    for k in ("gen_loss_adversarial", "gen_loss_recon_L1", "gen_loss_recon", "gen_loss", "discr_loss"):
+        a, b = float(model.last_logs["train_" + k]), float(ref[k])
+        tol = 2e-3 if k == "discr_loss" else 1e-3
+        assert abs(a - b) <= tol * max(1.0, abs(b)), (k, a, b)
+    # BatchNorm running statistics after the step: generator head (2 forward passes of 8 patches), PatchGAN (3 passes)
+    for (n, b_hip), (_, b_ref) in zip(sorted(dict(gen.named_buffers()).items()), sorted(dict(rgen.named_buffers()).items())):
+        if b_hip.dtype.is_floating_point and "bssfp" in n and "pc-" not in n:
+            torch.testing.assert_close(b_hip.cpu(), b_ref, rtol=2e-3, atol=2e-5, msg=n)

@@ -271,6 +271,12 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
   return MI355_OK;
 }
 
+// A kernel that declares more than 64 KB of dynamic LDS needs its limit raised once per process; 0 on success.  A failure
+// (another driver or LDS carve-out) is reported by name at the launch site instead of as a generic launch error later.
+static int raise_lds(const void* fn, int bytes) {
+  return (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
 template <typename T>
 int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
   ConvArgs a;
@@ -330,10 +336,9 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
       } else if (p.shape == 10) {
         if constexpr (sizeof(T) == 2) {
           static const int once = [] {
-            (void)hipFuncSetAttribute((const void*)conv_march_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MarchCfg<false>::LDS);
-            return (int)hipFuncSetAttribute((const void*)conv_march_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MarchCfg<true>::LDS);
+            return raise_lds((const void*)conv_march_kernel<false>, MarchCfg<false>::LDS) | raise_lds((const void*)conv_march_kernel<true>, MarchCfg<true>::LDS);
           }();
-          (void)once;
+          if (once) { mi355_set_error("conv_march: cannot raise the dynamic LDS limit to %d bytes (hip error %d)", MarchCfg<false>::LDS, once); return MI355_ERR_HIP; }
           MarchArgs m{p.seg_len, p.nseg, p.tiles_h, p.tiles_w, d->q_amax_x, d->q_amax_w};
           if (d->dtype == MI355_DT_FP8) conv_march_kernel<true><<<grid, block, MarchCfg<true>::LDS, st>>>(a, m);
           else conv_march_kernel<false><<<grid, block, MarchCfg<false>::LDS, st>>>(a, m);
@@ -341,10 +346,9 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
       } else if (p.shape == 11) {
         if constexpr (sizeof(T) == 2) {
           static const int once = [] {
-            (void)hipFuncSetAttribute((const void*)conv_marchg_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, MarchGCfg<4>::LDS);
-            return (int)hipFuncSetAttribute((const void*)conv_marchg_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, MarchGCfg<2>::LDS);
+            return raise_lds((const void*)conv_marchg_kernel<4>, MarchGCfg<4>::LDS) | raise_lds((const void*)conv_marchg_kernel<2>, MarchGCfg<2>::LDS);
           }();
-          (void)once;
+          if (once) { mi355_set_error("conv_marchg: cannot raise the dynamic LDS limit to %d bytes (hip error %d)", MarchGCfg<4>::LDS, once); return MI355_ERR_HIP; }
           MarchArgs m{p.seg_len, p.nseg, p.tiles_h, p.tiles_w, nullptr, nullptr};
           if (p.vt == 4) conv_marchg_kernel<4><<<grid, block, MarchGCfg<4>::LDS, st>>>(a, m);
           else conv_marchg_kernel<2><<<grid, block, MarchGCfg<2>::LDS, st>>>(a, m);
@@ -357,10 +361,9 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
       } else if (p.shape == 12 || p.shape == 13) {
         if constexpr (sizeof(T) == 2) {
           static const int once = [] {
-            (void)hipFuncSetAttribute((const void*)conv_lowg_kernel<4, 8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, LowGCfg<4, 8, 16>::LDS);
-            return (int)hipFuncSetAttribute((const void*)conv_lowg_kernel<8, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LowGCfg<8, 8, 8>::LDS);
+            return raise_lds((const void*)conv_lowg_kernel<4, 8, 16>, LowGCfg<4, 8, 16>::LDS) | raise_lds((const void*)conv_lowg_kernel<8, 8, 8>, LowGCfg<8, 8, 8>::LDS);
           }();
-          (void)once;
+          if (once) { mi355_set_error("conv_lowg: cannot raise the dynamic LDS limit to %d bytes (hip error %d)", LowGCfg<4, 8, 16>::LDS, once); return MI355_ERR_HIP; }
           if (p.shape == 12) conv_lowg_kernel<4, 8, 16><<<grid, block, LowGCfg<4, 8, 16>::LDS, st>>>(a);
           else conv_lowg_kernel<8, 8, 8><<<grid, block, LowGCfg<8, 8, 8>::LDS, st>>>(a);
         }

@@ -897,8 +897,8 @@ extern "C" int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream) {
   a.g_cls_cout = d->g_cls_cout;
   if (p.march) {
     const WMarchArgs m{p.seg_len, p.nseg, p.tiles_h, p.tiles_w, p.nslabs, p.ci_tiles, p.co_tiles};
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)wgrad_march_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWmLds); attr = true; }
+    static const int attr = (int)hipFuncSetAttribute((const void*)wgrad_march_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWmLds);
+    if (attr) { mi355_set_error("wgrad_march: cannot raise the dynamic LDS limit to %d bytes (hip error %d)", kWmLds, attr); return MI355_ERR_HIP; }
     wgrad_march_kernel<<<dim3(((p.nslabs + 7) / 8) * 8 * p.ci_tiles * p.co_tiles), dim3(256), kWmLds, st>>>(a, m);
   } else if (p.fast && p.deconv4) {
     const dim3 grid(p.splits, p.ci_tiles, p.co_tiles / kDeconvNco);

@@ -754,7 +754,11 @@ class NormActFn(Function):
         z = ops.as_act(z)
         n, d, h, w, c = z.shape
         rows = n * d * h * w
-        groups = n if cfg.kind == "instance" else (bn_groups if cfg.kind == "batch" else 1)
+        # statistics of the batch itself (instance norm; BatchNorm in training mode or without running statistics)?  In eval
+        # mode BatchNorm normalises every sample with the SAME running statistics: one (1, c) mean / rstd row, one group --
+        # whatever bn_groups says (a stacked forward_pair on a model in .eval(): ADVICE r3)
+        use_batch = cfg.kind == "instance" or (cfg.kind == "batch" and (training or running_mean is None))
+        groups = n if cfg.kind == "instance" else (bn_groups if (cfg.kind == "batch" and use_batch) else 1)
         assert n % groups == 0
         mean = rstd = None
         batch_stats = False
@@ -762,7 +766,7 @@ class NormActFn(Function):
         ctx.emit8_bwd = emit8_bwd if (emit8_bwd is not None and emit8_bwd.primed and not small and not s2d_out) else None
         if emit8 is not None and not (emit8.primed and not small and not s2d_out and z.dtype == torch.bfloat16 and c == 32):
             emit8 = None
-        if small and cfg.kind != "none" and (cfg.kind == "instance" or training or running_mean is None):
+        if small and cfg.kind != "none" and use_batch:
             # small tensor (low U-Net levels, last PatchGAN blocks): statistics, norm, dropout and activation in ONE launch
             if rows // groups <= 1:
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(z.shape)}")
@@ -784,7 +788,6 @@ class NormActFn(Function):
             ctx.meta = (groups, cfg.slope, p, seed, True, gamma.numel() if gamma is not None else 0)
             return a
         if cfg.kind != "none":
-            use_batch = cfg.kind == "instance" or training or running_mean is None
             if use_batch:
                 if rows // groups <= 1:
                     raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(z.shape)}")

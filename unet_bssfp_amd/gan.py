@@ -140,6 +140,15 @@ class bSSFPToDWITensorModel(nn.Module):
     def _discr_pair(self) -> bool:
         return self.pair_discriminator_calls and hasattr(self.discr, "forward_pair") and next(self.discr.parameters()).is_cuda
 
+    def _discr_uses(self, x, y) -> int:
+        """Gradient contributions every discriminator parameter receives in the discriminator phase: 1 when ``forward_pair``
+        takes its stacked pass, 2 when the phase is two calls (extents that are not multiples of 32, inputs that require
+        grad, pairing switched off).  Derived from the predicate ``forward_pair`` itself branches on -- announcing 1 while two
+        calls ran would let an eagerly attached bucket be all-reduced after the first call's contributions."""
+        if self._discr_pair() and self.discr.pair_single_pass(x, x.new_empty(0), y):   # (y_hat is detached: never requires grad)
+            return 1
+        return 2
+
     def _discr_step(self, x, y):
         y_hat = self.gen(x).detach()
         if self._discr_pair():
@@ -280,7 +289,7 @@ class bSSFPToDWITensorModel(nn.Module):
         x, y = self.unpack_batch(batch)
         self._toggle(self.gen, False)
         if self.sinks_discr is not None:
-            self.sinks_discr.begin_phase(1 if self._discr_pair() else 2)     # gradient contributions per parameter in this phase
+            self.sinks_discr.begin_phase(self._discr_uses(x, y))             # gradient contributions per parameter in this phase
         if staged:
             from .functional import StageBoundary
             self._stage_sinks = self.sinks_discr
@@ -465,17 +474,33 @@ class GraphedTrainingStep:
         for _ in range(max(2, warmup)):                     # eager: allocations, caches, optimiser state
             self._eager_step()
         torch.cuda.synchronize()
+        self._assert_fp8_slots_primed()
         self.logs: Dict[str, torch.Tensor] = {}
-        self.graphs = self._capture(batch, None)
+        self.graphs = self._capture(batch, None, self.logs)
         # further instances of the SAME step over other static input sets (``add_instance``): a feed that alternates between two
         # sets copies the next host batch straight into the set that is not running -- no staging buffer, no device-to-device
-        # copy at the step boundary (bench.py --fresh-batch; src/data_module.py:185-188 delivers a new batch every step)
-        self.instances = [(batch, self.graphs)]
+        # copy at the step boundary (bench.py --fresh-batch; src/data_module.py:185-188 delivers a new batch every step).
+        # Every instance keeps its OWN log tensors (its capture's outputs): ``__call__(i)`` points ``model.last_logs`` at them.
+        self.instances = [(batch, self.graphs, self.logs)]
         model.last_logs = self.logs
         torch.cuda.synchronize()
 
-    def _capture(self, batch, pool):
-        model, logs = self.model, self.logs
+    def _assert_fp8_slots_primed(self):
+        """Delayed-scaling slots (functional.Fp8Scales) carry HOST flags that a capture bakes in: a slot that is touched but
+        not yet primed would be captured on its first-step path (in-step amax pass) for ever.  The eager warm-up steps
+        (at least two) prime every slot the step uses; anything else is a programming error."""
+        import sys
+        fn = sys.modules.get(__package__ + ".functional")
+        if fn is None:
+            return
+        for chunks in fn.Fp8Scales._chunks.values():
+            for _table, slots in chunks:
+                bad = [i for i, s in enumerate(slots) if s.touched and not s.primed]
+                if bad:
+                    raise RuntimeError(f"fp8 delayed-scaling slots {bad} are in use but not primed at capture time")
+
+    def _capture(self, batch, pool, logs):
+        model = self.model
         if not self.segmented:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool, capture_error_mode=CAPTURE_MODE):
@@ -503,8 +528,9 @@ class GraphedTrainingStep:
         they must never run concurrently -- they do not: one stream, one replay at a time.  Returns the instance index for
         ``__call__(instance)``."""
         torch.cuda.synchronize()
-        graphs = self._capture(batch, self.graphs[0].pool())
-        self.instances.append((batch, graphs))
+        logs: Dict[str, torch.Tensor] = {}
+        graphs = self._capture(batch, self.graphs[0].pool(), logs)
+        self.instances.append((batch, graphs, logs))
         torch.cuda.synchronize()
         return len(self.instances) - 1
 
@@ -571,7 +597,7 @@ class GraphedTrainingStep:
                 after(0)
         else:
             self._segments(lambda i: graphs[i].replay(), after)
-        self.model.last_logs = self.logs
+        self.model.last_logs = self.instances[instance][2]
 
 
 def synthetic_batch(n: int, s, seed: int, modality: str = "bssfp", device="cpu"):

@@ -250,6 +250,14 @@ class Discriminator(_Mi355Module):
         z, _ = self.final.forward_act(h)
         return Fn.UnpackFn.apply(z, 1)
 
+    @staticmethod
+    def pair_single_pass(x, y_a, y_b) -> bool:
+        """Does ``forward_pair`` take its single stacked pass on these inputs (one gradient contribution per parameter), or
+        does it fall back to two calls (two contributions)?  The caller that announces the number of contributions to the
+        gradient buckets (gan._phase_discr -> GradBuckets.begin_phase) asks THIS predicate, so the two cannot diverge."""
+        return (all(e % 32 == 0 for e in x.shape[2:])
+                and not (x.requires_grad or y_a.requires_grad or y_b.requires_grad))
+
     def forward_pair(self, x, y_a, y_b, stacked: bool = False):
         """(self(x, y_a), self(x, y_b)) in ONE pass over the two inputs stacked along the batch -- the discriminator phase
         calls the network on the fake and on the real batch back to back (src/model.py:184-186).  Every BatchNorm normalises
@@ -263,8 +271,7 @@ class Discriminator(_Mi355Module):
         cin = x.shape[1] + y_a.shape[1]
         cp = round_up(cin, 16)
         blocks = (self.d1[self.modality], self.d2, self.d3, self.d4, self.d5)
-        s2d = all(e % 32 == 0 for e in x.shape[2:])
-        if not s2d or y_a.requires_grad or y_b.requires_grad or x.requires_grad:
+        if not self.pair_single_pass(x, y_a, y_b):
             return self(x, y_a), self(x, y_b)                       # (general case: two calls)
         d, hh, w = x.shape[2:]
         h = Fn._new_s2d(ops.s2d_shape(2 * n, d, hh, w, cp), self.compute_dtype, x.device)

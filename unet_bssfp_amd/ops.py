@@ -455,6 +455,10 @@ def _normact_desc(z, groups, mean, rstd, gamma, beta, slope, drop_p, seed, seed_
     rows = n * dd * h * w
     d.z, d.ldz, d.c = z.data_ptr(), act_ld(z), c
     d.rows_per_group, d.groups = rows // groups, groups
+    # the kernels read mean[g * c + ch] for every group g: a (1, c) row with groups > 1 would be an out-of-bounds read
+    for t in (mean, rstd):
+        if t is not None and t.numel() != groups * c:
+            raise ValueError(f"norm statistics hold {t.numel()} values for {groups} group(s) x {c} channels")
     d.mean, d.rstd, d.gamma, d.beta = _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta)
     d.n_affine = gamma.numel() if gamma is not None else 0
     d.slope, d.drop_p, d.seed = slope, drop_p, seed
