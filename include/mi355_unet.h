@@ -147,6 +147,12 @@ typedef struct mi355_conv_desc {
    * x0 is e4m3 of x * 224 / amax_x (mi355_cast_fp8: one byte per channel, ld0 in bytes), wp is packed with
    * MI355_DT_FP8, y / statistics are bf16 / f32 as in the bf16 mode.  Both amax pointers: device f32[1]. */
   const float* q_amax_x; const float* q_amax_w;
+  /* Accumulator start value (bf16 dense 2x2x2 stride-1 convolutions on the marching kernel only: PatchGAN blocks on
+   * space-to-depth tensors, src/model.py:72-82): z = conv(x) + addend + bias, fused statistics of conv(x) + addend.
+   * addend: f32 [n][do_][ho][wo][ld_add] (channels >= coutp), NULL = zeros.  y_f32 != 0: y is f32 (ldy in f32 elements)
+   * instead of the operand type -- the x-part of the PatchGAN's first block, computed once per training step, travels
+   * between two launches without a rounding.  Plans that cannot honour either field fail with MI355_ERR_UNSUPPORTED. */
+  const float* addend; int32_t ld_add; int32_t y_f32;
 } mi355_conv_desc;
 int mi355_conv_fwd(const mi355_conv_desc* d, void* stream);
 int64_t mi355_conv_workspace_bytes(const mi355_conv_desc* d);

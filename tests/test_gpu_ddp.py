@@ -34,9 +34,12 @@ def _worker(rank, world, port, mode, q):
         torch.manual_seed(10 + rank)                       # ranks start different: rank 0 is broadcast
         gen, discr = M.Generator("bssfp", dropout=0.0), M.Discriminator("bssfp")
         model = bSSFPToDWITensorModel("bssfp", gen=gen.to(dev), discr=discr.to(dev)).train()
-        size = 48 if mode.startswith("eager48") else 32
-        batch = synthetic_batch(2, size, seed=70 + rank, device=dev)
-        if mode == "eager48_nopair":
+        batch = synthetic_batch(2, 32, seed=70 + rank, device=dev)
+        if mode.startswith("eager_ygrad"):
+            # a target that requires grad: Discriminator.forward_pair falls back to two calls (as it does for extents that
+            # are not multiples of 32, where only the forward pass of the strided layers exists)
+            batch["dwi-tensor_orig"]["data"].requires_grad_(True)
+        if mode == "eager_ygrad_nopair":
             model.pair_discriminator_calls = False
         extra = None
         if mode == "graph":
@@ -68,7 +71,7 @@ def _worker(rank, world, port, mode, q):
             for i in range(3):
                 model.generator_only_step(batch, i)
             extra = list(model.sinks_gen.launch_order)
-        elif mode.startswith("eager48"):
+        elif mode.startswith("eager_ygrad"):
             ddp.attach(model)
             for i in range(2):
                 model.training_step(batch, i)
@@ -160,11 +163,11 @@ def test_zero_grad_on_sink_parameters_fails_loudly(hip):
 
 
 def test_discriminator_phase_as_two_calls_announces_two_contributions_two_ranks(hip):
-    """at extents that are not multiples of 32 (48^3) ``Discriminator.forward_pair`` falls back to two calls, so
-    every discriminator parameter receives TWO gradient contributions in the phase; the eagerly attached buckets must be
-    told so (an all-reduce launched after the first call's contributions would miss the second call's).  The default path
-    must equal the explicitly unpaired one bit for bit, on every rank."""
-    a, b = _run("eager48"), _run("eager48_nopair")
+    """when ``Discriminator.forward_pair`` falls back to two calls (an input that requires grad; extents that are
+    not multiples of 32), every discriminator parameter receives TWO gradient contributions in the phase; the eagerly
+    attached buckets must be told so (an all-reduce launched after the first call's contributions would miss the second
+    call's).  The default path must equal the explicitly unpaired one bit for bit, on every rank."""
+    a, b = _run("eager_ygrad"), _run("eager_ygrad_nopair")
     assert all(r[1] == "ok" for r in a + b), [r[1] for r in a + b]
     assert all(r[3] == [2] for r in a + b), [r[3] for r in a + b]
     assert a[0][2] == b[0][2]

@@ -33,7 +33,7 @@ class ConvDesc(C.Structure):
                 ("y", _vp), ("ldy", _i32), ("cstore", _i32), ("dy", _i32), ("hy", _i32), ("wy", _i32),
                 ("os", _i32), ("ooff", _i32 * 3), ("stats_part", _vp), ("dtype", _i32),
                 ("workspace", _vp), ("workspace_bytes", _i64), ("cls_cout", _i32), ("nbias", _i32),
-                ("q_amax_x", _vp), ("q_amax_w", _vp)]
+                ("q_amax_x", _vp), ("q_amax_w", _vp), ("addend", _vp), ("ld_add", _i32), ("y_f32", _i32)]
 
 
 class WgradDesc(C.Structure):

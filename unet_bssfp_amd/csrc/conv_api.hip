@@ -3,6 +3,7 @@
 #include "conv_kernels.h"
 #include "conv_march.h"
 #include "conv_marchg.h"
+#include "conv_march2.h"
 
 namespace {
 
@@ -31,6 +32,7 @@ int gcd_i(long long a, long long b) { while (b) { long long t = a % b; a = b; b 
 // 11 marchg (4 ROWS x 32 footprint marching along d, input channels in 32-channel groups, weights streamed through an LDS
 //    ring: conv_marchg_kernel<ROWS>; vt = ROWS)
 // 12 / 13 lowg (512-voxel tiles 4x8x16 / 8x8x8 x 64 output channels, weights through LDS once per workgroup: conv_lowg_kernel)
+// 14 march2 (dense 2x2x2 on wide tensors -- the PatchGAN on space-to-depth operands: conv_march2_kernel<ROWS>; vt = ROWS)
 const int kTD[14] = {2, 2, 4, 4, 2, 2, 4, 8, 4, 4, 0, 0, 4, 8}, kTH[14] = {4, 8, 8, 4, 4, 8, 4, 4, 4, 4, 0, 0, 8, 8},
           kTW[14] = {32, 16, 8, 32, 16, 8, 32, 32, 32, 32, 0, 0, 16, 8}, kVT[14] = {2, 2, 2, 4, 1, 1, 2, 4, 4, 4, 0, 0, 4, 4};
 
@@ -104,11 +106,51 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
                          (d->c0 + d->c1) >= 16 * tune_lowg_minch() && (long long)d->n * d->do_ * d->ho * d->wo >= 256 &&
                          d->wo <= tune_lowg_maxw();
     p->shape = (d->wo > 16 && !lowg_ok) ? 0 : (d->wo > 8 ? 1 : 2);       // (0: the wide-level plans below)
+    // dense k2 on wide bf16 tensors in whole 32-channel groups, plain output grid, padding 0 (forward on S(a)) or 1 (its data
+    // gradient): the marching k2 kernel when its footprints x d-segments fill (most of) the chip and the rows are not mostly
+    // tile padding.  Cost per workgroup and 32-channel group: (len + 1) input planes of fixed overhead + len output planes
+    // of 2 x 4 x 2 ROWS MFMAs.
+    bool march2 = false;
+    {
+      const int pd = d->pad[0];
+      const long long nvi = (long long)d->n * d->di * d->hi * d->wi, nvo = (long long)d->n * d->dy * d->hy * d->wy;
+      const bool ok = d->dtype == MI355_DT_BF16 && d->ks == 2 && d->c0 % 32 == 0 && d->c1 % 32 == 0 && d->os == 1 &&
+                      d->ooff[0] == 0 && d->ooff[1] == 0 && d->ooff[2] == 0 && (pd == 0 || pd == 1) && d->pad[1] == pd && d->pad[2] == pd &&
+                      d->do_ == d->di - 1 + 2 * pd && d->ho == d->hi - 1 + 2 * pd && d->wo == d->wi - 1 + 2 * pd &&
+                      d->dy == d->do_ && d->hy == d->ho && d->wy == d->wo && (d->cstore & 7) == 0 && d->wo >= 32 &&
+                      nvi * d->ld0 * 2 < (1ll << 31) && nvi * (d->c1 ? d->ld1 : 0) * 2 < (1ll << 31) &&
+                      nvo * d->ldy * (d->y_f32 ? 4 : 2) < (1ll << 31) && (!d->addend || nvo * d->ld_add * 4 < (1ll << 31)) &&
+                      forced_shape() != 0;
+      if (ok) {
+        long long best = -1; int best_len = 0, best_rows = 0;
+        for (int rows = 4; rows >= 2; rows -= 2) {
+          const int th = ceil_div(d->ho, 4 * rows), tw = ceil_div(d->wo, 32);
+          // (rows x columns the tiles cover against the ones that exist: S-layout gradients are 2^k + 1 wide)
+          if ((long long)th * 4 * rows * tw * 32 * 2 > 3ll * d->ho * d->wo) continue;
+          const long long fp = (long long)d->n * th * tw * (d->coutp / 32);
+          for (int ns = 1; ns <= d->do_ && ns <= 64; ++ns) {
+            const int len = ceil_div(d->do_, ns), segs = ceil_div(d->do_, len);
+            if (fp * segs < 128) continue;
+            const long long rounds = (fp * segs + 255) / 256, cost = rounds * ((len + 1) * 500ll + (long long)len * 512 * rows);
+            if (best < 0 || cost < best) { best = cost; best_len = len; best_rows = rows; }
+          }
+        }
+        if (best >= 0) {
+          march2 = true;
+          p->shape = 14;
+          p->seg_len = best_len;
+          p->nseg = ceil_div(d->do_, best_len);
+          p->vt = best_rows;
+        }
+      }
+    }
+    MI355_REQUIRE(march2 || (!d->addend && !d->y_f32), "conv: addend / y_f32 need the marching k2 plan (bf16, ks 2, 32-channel groups, wide rows)");
     auto count = [&](int sh, int ct) {
       return (long long)ceil_div(d->do_, kTD[sh]) * ceil_div(d->ho, kTH[sh]) * ceil_div(d->wo, kTW[sh]) * d->n *
              (d->coutp / (32 * ct));
     };
-    if (p->shape == 0) {
+    if (march2) {
+    } else if (p->shape == 0) {
       if ((d->dtype == MI355_DT_BF16 || d->dtype == MI355_DT_FP8) && d->ks == 3) {
         // wide bf16 3x3x3 layers: the row-reuse + LDS-DMA kernel (shape 9) when its 4x4x32 tiles fill the chip,
         // else 8-wave 4x4x32 tiles (shape 6) / the plain 2x4x32 tile.
@@ -196,7 +238,7 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
       p->tiles_d = p->nseg;
       p->tiles_h = ceil_div(d->ho, kMarchFH);
       p->tiles_w = ceil_div(d->wo, kMarchFW);
-    } else if (p->shape == 11) {
+    } else if (p->shape == 11 || p->shape == 14) {
       p->ct = 1;                                     // (vt = ROWS was set with the plan)
       p->tiles_d = p->nseg;
       p->tiles_h = ceil_div(d->ho, 4 * p->vt);
@@ -219,6 +261,7 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
     p->tiles_d = p->tiles_h = p->tiles_w = 0;
     p->shape = 0;
   }
+  MI355_REQUIRE(p->halo || (!d->addend && !d->y_f32), "conv: addend / y_f32 need the marching k2 plan");
   MI355_REQUIRE(d->dtype != MI355_DT_FP8 || (p->halo && p->shape == 10),
                 "conv: the fp8 path covers 3x3x3 stride-1 layers with 32 input channels in one source and a plain output grid");
   MI355_REQUIRE(p->tiles < (1ll << 31), "conv: too many tiles");
@@ -252,7 +295,7 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
       if (ks >= 2) set_split(ks);
     }
   }
-  if (p->halo && p->shape != 10 && p->shape != 11) {      // (the marching kernels walk the whole contraction themselves)
+  if (p->halo && p->shape != 10 && p->shape != 11 && p->shape != 14) {      // (the marching kernels walk the whole contraction themselves)
     // few output positions and a long contraction (8^3 / 16^3 U-Net levels, low PatchGAN levels): the
     // grid cannot fill 256 CUs and every workgroup streams its weights at one L2/HBM latency per tap
     // group => split the contraction over blockIdx.z and combine in a second kernel
@@ -368,6 +411,16 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
           else conv_lowg_kernel<8, 8, 8><<<grid, block, LowGCfg<8, 8, 8>::LDS, st>>>(a);
         }
       } else { HALO_KS(3) }
+    } else if (p.shape == 14) {
+      if constexpr (sizeof(T) == 2) {
+        static const int once = [] {
+          return raise_lds((const void*)conv_march2_kernel<4>, March2Cfg<4>::LDS) | raise_lds((const void*)conv_march2_kernel<2>, March2Cfg<2>::LDS);
+        }();
+        if (once) { mi355_set_error("conv_march2: cannot raise the dynamic LDS limit to %d bytes (hip error %d)", March2Cfg<4>::LDS, once); return MI355_ERR_HIP; }
+        March2Args m{p.seg_len, p.nseg, p.tiles_h, p.tiles_w, d->addend, d->ld_add, d->y_f32};
+        if (p.vt == 4) conv_march2_kernel<4><<<grid, block, March2Cfg<4>::LDS, st>>>(a, m);
+        else conv_march2_kernel<2><<<grid, block, March2Cfg<2>::LDS, st>>>(a, m);
+      }
     } else { HALO_KS(2) }
   } else if (sizeof(T) == 2 && p.pointwise) {
     // full-resolution 1x1x1 convs with <= 32 channels either side: persistent streaming kernel

@@ -189,7 +189,7 @@ def weight_pack_multi(descs):
 
 
 # ------------------------------------------------------------------------------ convolution
-def _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, stats, cls_cout=0, fp8=None):
+def _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, stats, cls_cout=0, fp8=None, addend=None):
     d = _lib.ConvDesc()
     n, di, hi, wi, c0 = x0.shape
     d.x0, d.c0, d.ld0 = x0.data_ptr(), c0, act_ld(x0)
@@ -216,11 +216,16 @@ def _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, st
     else:
         d.dtype = _DT[x0.dtype]
     d.cls_cout = cls_cout
+    # marching k2 kernel only (PatchGAN on space-to-depth tensors): accumulator start values / f32 output
+    d.y_f32 = 1 if (out.dtype == torch.float32 and x0.dtype != torch.float32) else 0
+    if addend is not None:
+        assert addend.dtype == torch.float32 and addend.dim() == 5 and tuple(addend.shape[:4]) == (n, *grid) and addend.stride(4) == 1
+        d.addend, d.ld_add = addend.data_ptr(), act_ld(addend)
     return d
 
 
-def conv_num_tiles(x0, x1, wp, coutp, ks, stride, pad, out, grid, os=1, ooff=(0, 0, 0), fp8=None) -> Tuple[int, int]:
-    d = _conv_desc(x0, x1, wp, coutp, None, ks, stride, pad, out, grid, os, ooff, None, 0, fp8)
+def conv_num_tiles(x0, x1, wp, coutp, ks, stride, pad, out, grid, os=1, ooff=(0, 0, 0), fp8=None, addend=None) -> Tuple[int, int]:
+    d = _conv_desc(x0, x1, wp, coutp, None, ks, stride, pad, out, grid, os, ooff, None, 0, fp8, addend)
     tiles, tps = C.c_int32(0), C.c_int32(0)
     _lib.check(_lib.load().mi355_conv_num_tiles(C.byref(d), C.byref(tiles), C.byref(tps)), "conv_num_tiles")
     return tiles.value, tps.value
@@ -232,15 +237,17 @@ CONV_PROBE = None
 
 
 def conv_fwd(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os=1, ooff=(0, 0, 0), stats=None, real=None,
-             cls_cout=0, fp8=None):
-    """fp8 = (amax_x, amax_w): x0 and wp hold e4m3 bytes (cast_fp8 / weight_pack(dtype=FP8)), `out` is bf16."""
-    require_cuda(x0, x1, wp, bias, out, stats)
+             cls_cout=0, fp8=None, addend=None):
+    """fp8 = (amax_x, amax_w): x0 and wp hold e4m3 bytes (cast_fp8 / weight_pack(dtype=FP8)), `out` is bf16.
+    addend (f32, the output's geometry): z = conv(x) + addend + bias; an f32 `out` on bf16 operands keeps the sums unrounded
+    (both: the marching k2 kernel, i.e. the PatchGAN's first block split into its x- and y-part)."""
+    require_cuda(x0, x1, wp, bias, out, stats, addend)
     if fp8 is None:
-        assert out.dtype == x0.dtype and wp.dtype == x0.dtype
+        assert (out.dtype == x0.dtype or out.dtype == torch.float32) and wp.dtype == x0.dtype
     else:
         assert x0.dtype == torch.uint8 and wp.dtype == torch.uint8 and out.dtype == torch.bfloat16 and x1 is None
     assert bias is None or (bias.dtype == torch.float32 and bias.is_contiguous())
-    d = _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, stats, cls_cout, fp8)
+    d = _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, stats, cls_cout, fp8, addend)
     lib = _lib.load()
     need = lib.mi355_conv_workspace_bytes(C.byref(d))
     if need < 0:
