@@ -153,6 +153,7 @@ typedef struct mi355_conv_desc {
    * instead of the operand type -- the x-part of the PatchGAN's first block, computed once per training step, travels
    * between two launches without a rounding.  Plans that cannot honour either field fail with MI355_ERR_UNSUPPORTED. */
   const float* addend; int32_t ld_add; int32_t y_f32;
+  int32_t add_n;                  /* samples held by addend: sample i of the grid starts from addend sample i % add_n (0 = n) */
 } mi355_conv_desc;
 int mi355_conv_fwd(const mi355_conv_desc* d, void* stream);
 int64_t mi355_conv_workspace_bytes(const mi355_conv_desc* d);
@@ -190,6 +191,9 @@ typedef struct mi355_wgrad_desc {
   int32_t g_cls_cout;                       /* >0: weight gradient of ConvTranspose3d(k2,s2) in one launch: GEMM column
                                                blk*g_cls_cout + co reads g at position 2p + (bd,bh,bw), channel co, and
                                                lands in tap (bd,bh,bw) of dw (ks must be 1, bf16 only) */
+  int32_t xn;                               /* >0: x holds xn samples and sample i of the grid reads x sample i % xn (one input
+                                               under several gradients: the PatchGAN's first block sees the same x in
+                                               both calls of the discriminator phase, src/model.py:184-186); 0 = n */
 } mi355_wgrad_desc;
 int64_t mi355_conv_wgrad_workspace(const mi355_wgrad_desc* d);
 int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream);

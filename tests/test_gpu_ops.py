@@ -573,6 +573,57 @@ def test_k4s2_conv_as_dense_k2_on_s2d(hip, dtype, n, cin, cout, sp):
     close_f32_sum(layer.bias.grad.cpu(), b_cpu.grad, "db")
 
 
+@pytest.mark.parametrize("ny,summed", [(1, True), (2, True), (2, False)])
+def test_split_s2d_conv_equals_the_conv_of_the_concatenation(hip, ny, summed):
+    """Fn.SplitS2dConvFn -- the PatchGAN's first block (src/model.py:72-73, 86-87: Conv3d(30, 32, k4, s2, p1) of cat([x, y], 1))
+    as x-part (f32, computed once, the accumulators' start value of the second launch) + y-part -- against torch's convolution
+    of the concatenation on the CPU: z, fused statistics, the gradient of the y part, the whole weight gradient (both channel
+    slices) and the bias gradient.  ny = 2: two stacked y batches over ONE x (Discriminator.forward_pair: add_n); the x-part of
+    the weight gradient then runs on the sum of the two gradients (default) or over x once per half (xn)."""
+    from unet_bssfp_amd import functional as Fn
+    Fn.SplitS2dConvFn.sum_pair_gradients = summed
+    dtype, cx, cy, cout, sp = torch.bfloat16, 24, 6, 32, (64, 64, 64)
+    g = torch.Generator().manual_seed(23)
+    layer = _conv_layer((cx + cy,), cout, 4, 2, 1, 6)
+    with torch.no_grad():
+        layer.weight.copy_(q(layer.weight, dtype))
+    x = q(torch.rand(1, cx, *sp, generator=g) - 0.3, dtype)
+    y = q(torch.rand(ny, cy, *sp, generator=g) - 0.3, dtype)
+    w_cpu = layer.weight.detach().clone().requires_grad_(True)
+    b_cpu = layer.bias.detach().clone().requires_grad_(True)
+    y_cpu = y.clone().requires_grad_(True)
+    z_ref = F.conv3d(torch.cat([x.expand(ny, -1, -1, -1, -1), y_cpu], 1), w_cpu, b_cpu, 2, 1)
+    gz = q(torch.rand(z_ref.shape, generator=g) - 0.5, dtype)
+    z_ref.backward(gz)
+    layer = layer.to(DEV)
+    sx, sy = to_s2d(x, dtype, 32), to_s2d(y, dtype, 8).requires_grad_(True)
+    plans = []
+    _ops().CONV_PROBE = lambda pid, d, real: plans.append((pid, bool(d.addend), d.y_f32, d.add_n))
+    try:
+        Fn.StepMemo.clear()
+        z, part = Fn.SplitS2dConvFn.apply(sx, sy, layer.weight, layer.bias, layer.spec, cx, cy, True)
+        z2, _ = Fn.SplitS2dConvFn.apply(sx, sy, layer.weight, layer.bias, layer.spec, cx, cy, False)     # x-part from the memo
+    finally:
+        _ops().CONV_PROBE = None
+    # x-part once (f32 out), y-part twice with the addend; all on the marching k2 kernel
+    assert [p[1:] for p in plans] == [(False, 1, 0), (True, 0, 1 if ny > 1 else 0), (True, 0, 1 if ny > 1 else 0)], plans
+    assert all((p[0] % 10000) // 100 == 24 for p in plans), plans
+    assert torch.equal(z, z2)
+    close(from_act(z, cout), z_ref.detach(), dtype, "z")
+    zc = z_ref.detach() - b_cpu.detach().view(1, -1, 1, 1, 1)
+    e0 = (part.sum(0).cpu()[0, :cout] - zc.sum((0, 2, 3, 4))).abs()
+    assert bool((e0 <= 2e-3 * ((zc.numel() / cout) * (zc * zc).sum((0, 2, 3, 4))).sqrt() + 1e-6).all()), e0.max()
+    close_f32_sum(part.sum(0).cpu()[1, :cout], (zc * zc).sum((0, 2, 3, 4)), "sum (z-b)^2")
+    try:
+        z.backward(to_act(gz, dtype))
+    finally:
+        Fn.SplitS2dConvFn.sum_pair_gradients = True
+    dy = _ops().unpack_ncdhw_s2d(sy.grad, cy, sp, 8, 0).cpu()
+    close(dy, y_cpu.grad, dtype, "dy")
+    close_f32_sum(layer.weight.grad.cpu(), w_cpu.grad, "dw")
+    close_f32_sum(layer.bias.grad.cpu(), b_cpu.grad, "db")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_normact_writes_and_reads_s2d(hip, dtype):
     from unet_bssfp_amd import functional as Fn

@@ -33,7 +33,7 @@ class ConvDesc(C.Structure):
                 ("y", _vp), ("ldy", _i32), ("cstore", _i32), ("dy", _i32), ("hy", _i32), ("wy", _i32),
                 ("os", _i32), ("ooff", _i32 * 3), ("stats_part", _vp), ("dtype", _i32),
                 ("workspace", _vp), ("workspace_bytes", _i64), ("cls_cout", _i32), ("nbias", _i32),
-                ("q_amax_x", _vp), ("q_amax_w", _vp), ("addend", _vp), ("ld_add", _i32), ("y_f32", _i32)]
+                ("q_amax_x", _vp), ("q_amax_w", _vp), ("addend", _vp), ("ld_add", _i32), ("y_f32", _i32), ("add_n", _i32)]
 
 
 class WgradDesc(C.Structure):
@@ -45,7 +45,7 @@ class WgradDesc(C.Structure):
                 ("workspace", _vp), ("workspace_bytes", _i64),
                 ("dw", _vp), ("cout", _i32), ("cin", _i32), ("s_co", _i64), ("s_ci", _i64), ("s_k", _i64 * 3),
                 ("tbase", _i32 * 3), ("tstep", _i32 * 3), ("accumulate", _i32), ("dtype", _i32), ("s2d_cp", _i32),
-                ("g_cls_cout", _i32)]
+                ("g_cls_cout", _i32), ("xn", _i32)]
 
 
 class NormActDesc(C.Structure):

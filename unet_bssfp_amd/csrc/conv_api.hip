@@ -119,7 +119,7 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
                       d->do_ == d->di - 1 + 2 * pd && d->ho == d->hi - 1 + 2 * pd && d->wo == d->wi - 1 + 2 * pd &&
                       d->dy == d->do_ && d->hy == d->ho && d->wy == d->wo && (d->cstore & 7) == 0 && d->wo >= 32 &&
                       nvi * d->ld0 * 2 < (1ll << 31) && nvi * (d->c1 ? d->ld1 : 0) * 2 < (1ll << 31) &&
-                      nvo * d->ldy * (d->y_f32 ? 4 : 2) < (1ll << 31) && (!d->addend || nvo * d->ld_add * 4 < (1ll << 31)) &&
+                      nvo * d->ldy * (d->y_f32 ? 4 : 2) < (1ll << 31) && (!d->addend || nvo * d->ld_add * 4 < (1ll << 31)) && d->add_n >= 0 &&
                       forced_shape() != 0;
       if (ok) {
         long long best = -1; int best_len = 0, best_rows = 0;
@@ -417,7 +417,7 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
           return raise_lds((const void*)conv_march2_kernel<4>, March2Cfg<4>::LDS) | raise_lds((const void*)conv_march2_kernel<2>, March2Cfg<2>::LDS);
         }();
         if (once) { mi355_set_error("conv_march2: cannot raise the dynamic LDS limit to %d bytes (hip error %d)", March2Cfg<4>::LDS, once); return MI355_ERR_HIP; }
-        March2Args m{p.seg_len, p.nseg, p.tiles_h, p.tiles_w, d->addend, d->ld_add, d->y_f32};
+        March2Args m{p.seg_len, p.nseg, p.tiles_h, p.tiles_w, d->addend, d->ld_add, d->y_f32, d->add_n};
         if (p.vt == 4) conv_march2_kernel<4><<<grid, block, March2Cfg<4>::LDS, st>>>(a, m);
         else conv_march2_kernel<2><<<grid, block, March2Cfg<2>::LDS, st>>>(a, m);
       }

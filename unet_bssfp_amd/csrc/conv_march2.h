@@ -35,7 +35,7 @@ template <int ROWS> struct March2Cfg {
   static constexpr int LDS = 2 * PLANE + WSLOTS * WUNIT + MISC + NI * 1024;
 };
 
-struct March2Args { int seg_len, nseg, tiles_h, tiles_w; const float* addend; int ld_add; int y_f32; };
+struct March2Args { int seg_len, nseg, tiles_h, tiles_w; const float* addend; int ld_add; int y_f32; int add_n; };
 
 template <int ROWS>
 __global__ __launch_bounds__(256, 1) void conv_march2_kernel(const ConvArgs a, const March2Args m) {
@@ -129,14 +129,15 @@ __global__ __launch_bounds__(256, 1) void conv_march2_kernel(const ConvArgs a, c
   const auto rsy = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (int)((((long long)a.n * a.dy * a.hy * a.wy - 1) * a.ldy + a.cstore) * esz), 0x00020000);
   const int yrow = ((ROWS * wave) * a.wy + w0 + r) * a.ldy * esz + cch * esz;
   // the addend: f32 [n][do][ho][wo][ld_add], this lane's 16 channels of voxel (q, h0 + ROWS wave + row, w0 + r)
+  const int nadd = m.add_n > 0 ? m.add_n : a.n, tna = tn % nadd;       // (one addend under several samples: Discriminator.forward_pair)
   const auto rsa = __builtin_amdgcn_make_buffer_rsrc((void*)m.addend, 0,
-                                                     m.addend ? (int)((((long long)a.n * a.do_ * a.ho * a.wo - 1) * m.ld_add + a.coutp) * 4) : 0, 0x00020000);
+                                                     m.addend ? (int)((((long long)nadd * a.do_ * a.ho * a.wo - 1) * m.ld_add + a.coutp) * 4) : 0, 0x00020000);
   const int arow = ((ROWS * wave) * a.wo + w0 + r) * m.ld_add * 4 + cch * 4;
   typedef float f32x4v __attribute__((ext_vector_type(4)));
   // (re)initialise row `row` of a set for the output plane q it starts next: the addend's values, or zeros
   auto init_row = [&](f32x16 (&s)[ROWS], int q, const int row) __attribute__((always_inline)) {
     const bool ok = m.addend != nullptr && q >= d0 && q < d1 && vox_ok && h0 + ROWS * wave + row < a.ho;
-    const int off = ok ? ((tn * a.do_ + q) * a.ho + h0) * a.wo * m.ld_add * 4 + arow + row * a.wo * m.ld_add * 4 : (int)0x80000000;
+    const int off = ok ? ((tna * a.do_ + q) * a.ho + h0) * a.wo * m.ld_add * 4 + arow + row * a.wo * m.ld_add * 4 : (int)0x80000000;
     if (m.addend != nullptr) {
 #pragma unroll
       for (int i4 = 0; i4 < 4; ++i4) {

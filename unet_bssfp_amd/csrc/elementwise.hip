@@ -1147,7 +1147,7 @@ int mi355_unpack_ncdhw(const void* src, float* dst, int32_t n, int32_t c, int64_
 
 static int check_s2d(int d, int h, int w, int cblk, int ld, const char* who) {
   MI355_REQUIRE(d > 0 && h > 0 && w > 0 && d % 2 == 0 && h % 2 == 0 && w % 2 == 0, "%s: space-to-depth needs even extents", who);
-  MI355_REQUIRE(cblk > 0 && cblk % 16 == 0 && ld >= 8 * cblk, "%s: space-to-depth row must hold 8 channel blocks", who);
+  MI355_REQUIRE(cblk > 0 && cblk % 8 == 0 && ld >= 8 * cblk, "%s: space-to-depth row must hold 8 channel blocks (of a multiple of 8 channels)", who);
   return MI355_OK;
 }
 
@@ -1186,7 +1186,7 @@ int mi355_weight_pack(const mi355_wpack_desc* d, void* stream) {
   MI355_REQUIRE(d && d->src && d->dst, "weight_pack: null pointer");
   MI355_REQUIRE(d->coutp % 32 == 0 && d->cinp % 16 == 0 && d->cout <= d->coutp && d->cin <= d->cinp && d->ks >= 1 && d->ks <= 4,
                 "weight_pack: bad extents");
-  MI355_REQUIRE(d->s2d_mode >= 0 && d->s2d_mode <= 2 && (d->s2d_mode == 0 || (d->s2d_cp > 0 && d->s2d_cp % 16 == 0)),
+  MI355_REQUIRE(d->s2d_mode >= 0 && d->s2d_mode <= 2 && (d->s2d_mode == 0 || (d->s2d_cp > 0 && d->s2d_cp % 8 == 0)),
                 "weight_pack: bad space-to-depth mode");
   MI355_REQUIRE(d->dtype == MI355_DT_F32 || d->dtype == MI355_DT_BF16 || d->dtype == MI355_DT_FP8, "weight_pack: bad dtype");
   MI355_REQUIRE(d->dtype != MI355_DT_FP8 || d->q_amax, "weight_pack: fp8 packing needs q_amax");
@@ -1325,7 +1325,7 @@ static int fill_wpack(const mi355_wpack_desc* d, WpackArgs* a) {
   MI355_REQUIRE(d && d->src && d->dst, "weight_pack: null pointer");
   MI355_REQUIRE(d->coutp % 32 == 0 && d->cinp % 16 == 0 && d->cout <= d->coutp && d->cin <= d->cinp && d->ks >= 1 && d->ks <= 4,
                 "weight_pack: bad extents");
-  MI355_REQUIRE(d->s2d_mode >= 0 && d->s2d_mode <= 2 && (d->s2d_mode == 0 || (d->s2d_cp > 0 && d->s2d_cp % 16 == 0)),
+  MI355_REQUIRE(d->s2d_mode >= 0 && d->s2d_mode <= 2 && (d->s2d_mode == 0 || (d->s2d_cp > 0 && d->s2d_cp % 8 == 0)),
                 "weight_pack: bad space-to-depth mode");
   a->src = d->src; a->dst = d->dst; a->cout = d->cout; a->cin = d->cin; a->coutp = d->coutp; a->cinp = d->cinp; a->ks = d->ks;
   a->s_co = d->s_co; a->s_ci = d->s_ci; a->s_k0 = d->s_k[0]; a->s_k1 = d->s_k[1]; a->s_k2 = d->s_k[2];

@@ -27,6 +27,7 @@ struct WgradArgs {
   int tap_groups;
   long long rows;        // n*do*ho
   int g_cls_cout;        // fast kernel, KS=1: GEMM column blk*g_cls_cout + co reads g at 2p + bits(blk)
+  int xn;                // samples held by x: grid sample n reads x sample n % xn
 };
 
 template <typename T> __device__ __forceinline__ float ld1(const char* p, long long idx) {
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
       const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
       const int id = od * a.stride + kd - a.pd, ih = oh * a.stride + kh - a.ph;
       const bool ok = tap < NT && id >= 0 && id < a.di && ih >= 0 && ih < a.hi;
-      xrow[t] = ok ? (((long long)n * a.di + id) * a.hi + ih) * a.wi : -1;
+      xrow[t] = ok ? (((long long)(n % a.xn) * a.di + id) * a.hi + ih) * a.wi : -1;
       kwv[t] = kw - a.pw;
     }
     for (int ow = h; ow < a.wo + h; ow += 2) {   // both halves iterate the same trip count
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradArgs a, i
       const int hw = row % HW, hh = (row / HW) % HH, hd = row / (HW * HH);
       const int gd = d0 + hd - a.pd, gh = h0 + hh - a.ph, gw = w0 + hw - a.pw;
       const bool ok = p < XROWS * 4 && part * 8 < cx_lim && gd >= 0 && gd < a.di && gh >= 0 && gh < a.hi && gw >= 0 && gw < a.wi;
-      sx[i] = ok ? *reinterpret_cast<const uint4*>(xsrc + (((((long long)n * a.di + gd) * a.hi + gh) * a.wi + gw) * ldx + cix + part * 8) * 2)
+      sx[i] = ok ? *reinterpret_cast<const uint4*>(xsrc + (((((long long)(n % a.xn) * a.di + gd) * a.hi + gh) * a.wi + gw) * ldx + cix + part * 8) * 2)
                  : make_uint4(0, 0, 0, 0);
     }
     __syncthreads();                      // every wave finished reading the previous tile
@@ -776,8 +777,9 @@ int wplan(const mi355_wgrad_desc* d, WPlan* p) {
   MI355_REQUIRE(d->c0 > 0 && d->c0 % 16 == 0 && d->c1 % 16 == 0 && d->cg % 16 == 0, "wgrad: channels must be multiples of 16");
   MI355_REQUIRE(d->c1 == 0 || (d->x1 && d->c0 % 32 == 0), "wgrad: concat split must be a multiple of 32");
   MI355_REQUIRE(d->cin <= d->c0 + d->c1 && d->cout <= d->cg, "wgrad: real extents exceed padded ones");
-  MI355_REQUIRE(d->s2d_cp == 0 || (d->s2d_cp % 16 == 0 && d->c1 == 0 && d->c0 == 8 * d->s2d_cp && d->cin <= d->s2d_cp),
+  MI355_REQUIRE(d->s2d_cp == 0 || (d->s2d_cp % 8 == 0 && d->c1 == 0 && d->c0 == 8 * d->s2d_cp && d->cin <= d->s2d_cp),
                 "wgrad: bad space-to-depth operand");
+  MI355_REQUIRE(d->xn >= 0 && (d->xn == 0 || d->n % d->xn == 0), "wgrad: xn must divide n");
   p->ks = d->ks;
   p->tpw = d->ks == 1 ? 1 : (d->ks == 3 ? 9 : 8);
   const int nt = d->ks * d->ks * d->ks;
@@ -895,6 +897,8 @@ extern "C" int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream) {
   a.slab = d->workspace; a.cinp = p.cinp32; a.coutp = p.coutp32;
   a.splits = p.splits; a.tap_groups = p.tap_groups; a.rows = p.rows;
   a.g_cls_cout = d->g_cls_cout;
+  a.xn = d->xn > 0 ? d->xn : d->n;
+  MI355_REQUIRE(a.xn == d->n || (!p.march && !(p.fast && p.deconv4)), "wgrad: xn is not supported by this plan");
   if (p.march) {
     const WMarchArgs m{p.seg_len, p.nseg, p.tiles_h, p.tiles_w, p.nslabs, p.ci_tiles, p.co_tiles};
     static const int attr = (int)hipFuncSetAttribute((const void*)wgrad_march_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWmLds);

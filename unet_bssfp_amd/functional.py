@@ -52,7 +52,7 @@ class LayerCache:
     def stale(self):
         """Entries whose weights changed since they were packed (and whose buffers can be re-packed in place)."""
         return [e for e in self._store.values() if e[0] != self._tag(e[2]) and e[3] is not None and e[3].dst == e[1][0].data_ptr()
-                and e[3].src == e[2].data_ptr()]
+                and e[3].src - getattr(e[3], "_src_off", 0) == e[2].data_ptr()]
 
     def clear(self):
         self._store.clear()
@@ -493,6 +493,20 @@ class ConvSpec:
             w.detach(), self.cin, self.cout, 2, k ** 3, self.cin * k ** 3, (k * k, k, 1), (2, 2, 2), (-2, -2, -2),
             dtype, cinp=cinp, coutp=8 * cp, s2d_mode=2, s2d_cp=cp, reuse=r))
 
+    # channel slice [c_off, c_off + c_n) of the k4 s2 p1 weight in the space-to-depth packings (the PatchGAN's first block
+    # split into the parts of cat([x, y], 1): SplitS2dConvFn)
+    def w_fwd_s2d_part(self, w, dtype, cp, c_off, c_n):
+        k = self.ks
+        return self.cache.get(("fwd_s2d_part", dtype, cp, c_off, c_n), w, lambda r: ops.weight_pack(
+            w.detach(), self.cout, c_n, 2, self.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (2, 2, 2),
+            dtype, cinp=8 * cp, s2d_mode=1, s2d_cp=cp, reuse=r, src_offset=c_off * k ** 3))
+
+    def w_dgrad_s2d_part(self, w, dtype, cinp, cp, c_off, c_n):
+        k = self.ks
+        return self.cache.get(("dgrad_s2d_part", dtype, cinp, cp, c_off, c_n), w, lambda r: ops.weight_pack(
+            w.detach(), c_n, self.cout, 2, k ** 3, self.cin * k ** 3, (k * k, k, 1), (2, 2, 2), (-2, -2, -2),
+            dtype, cinp=cinp, coutp=8 * cp, s2d_mode=2, s2d_cp=cp, reuse=r, src_offset=c_off * k ** 3))
+
     def out_extent(self, e):
         if self.kind == "deconv2":
             return 2 * e
@@ -697,6 +711,125 @@ class ConvFn(Function):
         return dx0, dx1, dw, db, None, None, None, None, None
 
 
+class StepMemo:
+    """Tensors computed once per training step and reused inside it, keyed by the objects they were computed from; emptied
+    at the start of every step like PackMemo (``DropoutState.advance``).  Holds the x-part of the PatchGAN's first block
+    (SplitS2dConvFn): the same batch x and the same discriminator weights enter D in the generator phase and in both calls
+    of the discriminator phase (src/model.py:172,184-186)."""
+    _store = {}
+
+    @classmethod
+    def get(cls, key_tensors, tag):
+        e = cls._store.get(tuple(id(t) for t in key_tensors))
+        if e is not None and all(r() is t for r, t in zip(e[0], key_tensors)) and e[1] == tag:
+            return e[2]
+        return None
+
+    @classmethod
+    def put(cls, key_tensors, tag, value):
+        if len(cls._store) >= 8:
+            cls._store.clear()
+        cls._store[tuple(id(t) for t in key_tensors)] = ([weakref.ref(t) for t in key_tensors], tag, value)
+
+    @classmethod
+    def clear(cls):
+        cls._store.clear()
+
+
+class SplitS2dConvFn(Function):
+    """z = Conv3d(k4, s2, p1)(cat([x, y], 1)) + bias with the two parts of the concatenation as separate space-to-depth
+    operands sx = S(x) (constant: no gradient) and sy = S(y): the convolution is linear in its input, so
+    z = conv(sx; W[:, :cx]) + conv(sy; W[:, cx:]) + bias.  The x-part is an f32 tensor computed ONCE per training step
+    (StepMemo) and enters the y-part's launch as the accumulators' start value (conv_march2_kernel: `addend`): the
+    PatchGAN's first block (src/model.py:72-73, 86-87) then costs one 24-channel convolution per step plus three 6-channel
+    ones, instead of three 30-channel ones -- and S(x) is packed once instead of three times, the data gradient covers the 6
+    y channels only, and the x-part of the weight gradient runs over x once (both halves of a stacked pair read the same
+    x: ``xn``).  sx may hold fewer samples than sy (forward_pair stacks two calls over one x)."""
+
+    sum_pair_gradients = True       # False: the x-part's weight gradient reads x once per half instead (`xn`; exact, twice the work)
+
+    @staticmethod
+    def forward(ctx, sx, sy, weight, bias, spec: ConvSpec, cx: int, cy: int, want_stats: bool):
+        sx, sy = ops.as_act(sx), ops.as_act(sy)
+        nx, ny = sx.shape[0], sy.shape[0]
+        assert ny % nx == 0 and sx.shape[1:4] == sy.shape[1:4] and spec.cin == cx + cy
+        di, hi, wi = sy.shape[1:4]
+        grid = (di - 1, hi - 1, wi - 1)
+        dtype, dev = sy.dtype, sy.device
+        cpx, cpy = sx.shape[4] // 8, sy.shape[4] // 8
+        cp = round_up(spec.cout, 16)
+        tag = LayerCache._tag(weight)
+        px = StepMemo.get((sx, weight), tag)
+        if px is None:
+            wpx, coutp, _ = spec.w_fwd_s2d_part(weight, dtype, cpx, 0, cx)
+            px = torch.empty((nx, *grid, coutp), dtype=torch.float32, device=dev)
+            ops.conv_fwd(sx, None, wpx, coutp, None, 2, 1, (0, 0, 0), px, grid, real=(cx, spec.cout))
+            StepMemo.put((sx, weight), tag, px)
+        wpy, coutp, _ = spec.w_fwd_s2d_part(weight, dtype, cpy, cx, cy)
+        out = ops.new_act(ny, *grid, cp, dtype, dev)
+        part = None
+        bp = bias.detach() if bias is not None else None
+        if want_stats:
+            tiles, _ = ops.conv_num_tiles(sy, None, wpy, coutp, 2, 1, (0, 0, 0), out, grid, addend=px)
+            part = torch.empty((tiles, 2, coutp), dtype=torch.float32, device=dev)
+        ops.conv_fwd(sy, None, wpy, coutp, bp, 2, 1, (0, 0, 0), out, grid, stats=part, addend=px, real=(cy, spec.cout))
+        ctx.save_for_backward(sx, sy, weight)
+        ctx.spec, ctx.cx, ctx.cy = spec, cx, cy
+        ctx.bias_param, ctx.weight_param = bias, weight
+        if part is None:
+            part = torch.empty((0,), dtype=torch.float32, device=dev)
+        ctx.mark_non_differentiable(part)
+        ctx.set_materialize_grads(False)
+        return out, part
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz, _dpart):
+        if dz is None:
+            return (None,) * 8
+        sx, sy, weight = ctx.saved_tensors
+        spec, cx, cy = ctx.spec, ctx.cx, ctx.cy
+        dz = ops.as_act(dz)
+        ny, di, hi, wi, _ = sy.shape
+        grid = tuple(dz.shape[1:4])
+        dtype, dev = sy.dtype, sy.device
+        cpx, cpy = sx.shape[4] // 8, sy.shape[4] // 8
+        k = spec.ks
+        dsy = dw = db = None
+        if ctx.needs_input_grad[1]:
+            wp, coutp, _ = spec.w_dgrad_s2d_part(weight, dtype, dz.shape[4], cpy, cx, cy)
+            dsy = ops.new_act(ny, di, hi, wi, 8 * cpy, dtype, dev)
+            ops.conv_fwd(dz, None, wp, coutp, None, 2, 1, (1, 1, 1), dsy, (di, hi, wi), real=(spec.cout, cy))
+        if ctx.needs_input_grad[2]:
+            weight = ctx.weight_param
+            wsink = sink_of(weight)
+            acc = wsink is not None and not wsink.fresh(weight)
+            dwt = sink_grad(weight) if wsink is not None else torch.empty_like(weight, dtype=torch.float32)
+            geo = (spec.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (2, 2, 2))
+            nx = sx.shape[0]
+            if ny == 2 * nx and SplitS2dConvFn.sum_pair_gradients:
+                # both halves of a stacked pair saw the SAME x: x (*) dz_a + x (*) dz_b = x (*) (dz_a + dz_b) -- half the x-part's
+                # weight-gradient work for one pass over the two gradients (the sum is formed in f32 and rounded to bf16 once)
+                ops.conv_wgrad(sx, None, torch.add(dz[:nx], dz[nx:]), grid, 1, (0, 0, 0), 2, 1, (0, 0, 0), dwt, spec.cout, cx, *geo,
+                               s2d_cp=cpx, accumulate=acc)
+            else:
+                ops.conv_wgrad(sx, None, dz, grid, 1, (0, 0, 0), 2, 1, (0, 0, 0), dwt, spec.cout, cx, *geo, s2d_cp=cpx, accumulate=acc, n=ny)
+            ops.conv_wgrad(sy, None, dz, grid, 1, (0, 0, 0), 2, 1, (0, 0, 0), dwt, spec.cout, cy, *geo, s2d_cp=cpy, accumulate=acc,
+                           dw_offset=cx * k ** 3)
+            if wsink is not None:
+                wsink.written(weight)
+            else:
+                dw = dwt
+        if ctx.bias_param is not None and ctx.needs_input_grad[3]:
+            bsink = sink_of(ctx.bias_param)
+            if bsink is not None:
+                ops.colsum_into(dz, sink_grad(ctx.bias_param), accumulate=not bsink.fresh(ctx.bias_param))
+                bsink.written(ctx.bias_param)
+            else:
+                db = ops.colsum(dz)[: spec.cout].contiguous()
+        return None, dsy, dw, db, None, None, None, None
+
+
 # ====================================================================================== norm + act
 class NormCfg:
     def __init__(self, kind, channels, eps=1e-5, momentum=0.1, slope=1.0, p=0.0):
@@ -730,6 +863,7 @@ class DropoutState:
         cls.base(device).add_(1)
         cls._salt = 0
         PackMemo.clear()                    # a new training step: constant inputs are packed afresh
+        StepMemo.clear()
         ColSumSide.clear()
         Fp8Scales.advance(device)           # ... and the e4m3 scales gathered in the last step come into use
 

@@ -187,16 +187,21 @@ class DownSampleConv(_Mi355Module):
         self.cfg = Fn.NormCfg("batch" if batchnorm else "none", out_channels, eps=1e-5, momentum=0.1,
                               slope=0.2 if activation else 1.0)
 
-    def forward_act(self, x0, x1=None, s2d_cp=0, s2d_out=False, bn_groups=1):
+    def forward_act(self, x0, x1=None, s2d_cp=0, s2d_out=False, bn_groups=1, split=None):
         """s2d_cp > 0: x0 is the space-to-depth tensor S(a) with s2d_cp channels per block (k4 s2 p1 only);
         s2d_out: return S(output) for the next k4 s2 p1 block instead of the plain activation;
-        bn_groups: BatchNorm statistics per consecutive sample group (Discriminator.forward_pair)."""
+        bn_groups: BatchNorm statistics per consecutive sample group (Discriminator.forward_pair);
+        split = (cx, cy): x0 = S(x) and x1 = S(y) are the two parts of cat([x, y], 1), x constant (Fn.SplitS2dConvFn)."""
         fuse = self.batchnorm and self.training
-        n, di, hi, wi = x0.shape[:4]
-        ext = (di - 1, hi - 1, wi - 1) if s2d_cp else tuple(self.conv.spec.out_extent(e) for e in (di, hi, wi))
+        n, di, hi, wi = (x1 if split else x0).shape[:4]
+        ext = (di - 1, hi - 1, wi - 1) if (s2d_cp or split) else tuple(self.conv.spec.out_extent(e) for e in (di, hi, wi))
         # small outputs (the last PatchGAN blocks): the norm kernel computes the statistics itself, in one launch
         small = fuse and ops.norm_is_small(n, *ext, round_up(self.conv.out_channels, 16), bn_groups)
-        z, part = self.conv.forward_act(x0, x1, want_stats=fuse and not small, zero_bias_grad=fuse, s2d_cp=s2d_cp)
+        if split:
+            z, part = Fn.SplitS2dConvFn.apply(x0, x1, self.conv.weight, self.conv.bias, self.conv.spec, split[0], split[1],
+                                              fuse and not small)
+        else:
+            z, part = self.conv.forward_act(x0, x1, want_stats=fuse and not small, zero_bias_grad=fuse, s2d_cp=s2d_cp)
         if not (self.batchnorm or self.activation):
             assert not s2d_out
             return z
@@ -235,9 +240,17 @@ class Discriminator(_Mi355Module):
         if all(e % 32 == 0 for e in x.shape[2:]):
             # k4 s2 p1 == dense k2 s1 on space-to-depth tensors: every block reads S(prev) and writes
             # S(own output), so the whole PatchGAN runs on the stride-1 implicit-GEMM kernels
-            h = Fn.PackFn.apply(-cp, self.compute_dtype, x, y)          # cat([x, y], 1) + layout + s2d
+            split = self._split_first_block(x, y, x.shape[0])
+            if split:
+                h = self._packed_x(x, split[2])                         # S(x): constant, packed once per training step
+                h1 = Fn.PackFn.apply(-split[3], self.compute_dtype, y)  # S(y): the part that changes (and may need a gradient)
+            else:
+                h = Fn.PackFn.apply(-cp, self.compute_dtype, x, y)      # cat([x, y], 1) + layout + s2d
             for i, blk in enumerate(blocks):
-                h = blk.forward_act(h, s2d_cp=cp, s2d_out=i < 4)
+                if i == 0 and split:
+                    h = blk.forward_act(h, h1, s2d_out=True, split=split[:2])
+                else:
+                    h = blk.forward_act(h, s2d_cp=cp, s2d_out=i < 4)
                 cp = round_up(blk.conv.out_channels, 16)
                 if i == 1 and blk.conv.weight.requires_grad:                    # (not while D is frozen in the generator phase)
                     Fn.StageBoundary.mark(h)                            # backward stage cut: {final, d5, d4, d3} | {d2, d1}
@@ -249,6 +262,30 @@ class Discriminator(_Mi355Module):
                     Fn.StageBoundary.mark(h)
         z, _ = self.final.forward_act(h)
         return Fn.UnpackFn.apply(z, 1)
+
+    split_first_block = True      # bf16: the first block as x-part (once per step) + y-part (Fn.SplitS2dConvFn)
+
+    def _split_first_block(self, x, y, n_grid):
+        """(cx, cy, cp_x, cp_y) when the first block runs split into the parts of cat([x, y], 1) (Fn.SplitS2dConvFn: bf16 mode,
+        x constant, both parts on the marching k2 kernel), else None."""
+        blk = self.d1[self.modality]
+        cx, cy = x.shape[1], y.shape[1]
+        if (not self.split_first_block or self.compute_dtype != torch.bfloat16 or x.requires_grad or blk.batchnorm
+                or blk.conv.in_channels != cx + cy):
+            return None
+        cpx, cpy = round_up(cx, 16), round_up(cy, 8)     # (8 blocks of 8 channels: 64 space-to-depth channels for the 6 of y)
+        se = tuple(e // 2 + 1 for e in x.shape[2:])
+        coutp = round_up(blk.conv.out_channels, 32)
+        if not (ops.conv_k2_marches(x.shape[0], se, 8 * cpx, coutp) and ops.conv_k2_marches(n_grid, se, 8 * cpy, coutp)):
+            return None
+        return cx, cy, cpx, cpy
+
+    def _packed_x(self, x, cpx):
+        hit = Fn.PackMemo.get(x, -cpx, self.compute_dtype)
+        if hit is None:
+            hit = Fn.PackFn.apply(-cpx, self.compute_dtype, x.detach())
+            Fn.PackMemo.put(x, -cpx, self.compute_dtype, hit)
+        return hit
 
     @staticmethod
     def pair_single_pass(x, y_a, y_b) -> bool:
@@ -274,12 +311,22 @@ class Discriminator(_Mi355Module):
         if not self.pair_single_pass(x, y_a, y_b):
             return self(x, y_a), self(x, y_b)                       # (general case: two calls)
         d, hh, w = x.shape[2:]
-        h = Fn._new_s2d(ops.s2d_shape(2 * n, d, hh, w, cp), self.compute_dtype, x.device)
-        x32 = x.detach().to(torch.float32).contiguous()
-        for half, y in enumerate((y_a, y_b)):
-            ops.pack2(x32, y.detach().to(torch.float32).contiguous(), h[half * n:(half + 1) * n], 0, cp, s2d_cblk=cp)
+        split = self._split_first_block(x, y_a, 2 * n)
+        if split:
+            h = self._packed_x(x, split[2])                         # ONE S(x) under both halves of the stacked S(y)
+            h1 = Fn._new_s2d(ops.s2d_shape(2 * n, d, hh, w, split[3]), self.compute_dtype, x.device)
+            for half, y in enumerate((y_a, y_b)):
+                ops.pack_ncdhw_s2d(y.detach().to(torch.float32).contiguous(), h1[half * n:(half + 1) * n], split[3], 0, split[3])
+        else:
+            h = Fn._new_s2d(ops.s2d_shape(2 * n, d, hh, w, cp), self.compute_dtype, x.device)
+            x32 = x.detach().to(torch.float32).contiguous()
+            for half, y in enumerate((y_a, y_b)):
+                ops.pack2(x32, y.detach().to(torch.float32).contiguous(), h[half * n:(half + 1) * n], 0, cp, s2d_cblk=cp)
         for i, blk in enumerate(blocks):
-            h = blk.forward_act(h, s2d_cp=cp, s2d_out=i < 4, bn_groups=2)
+            if i == 0 and split:
+                h = blk.forward_act(h, h1, s2d_out=True, bn_groups=2, split=split[:2])
+            else:
+                h = blk.forward_act(h, s2d_cp=cp, s2d_out=i < 4, bn_groups=2)
             cp = round_up(blk.conv.out_channels, 16)
             if i == 1 and blk.conv.weight.requires_grad:
                 Fn.StageBoundary.mark(h)

@@ -144,8 +144,8 @@ FP8 = "fp8"       # dtype marker of the e4m3 packings / operands (stored as torc
 def weight_pack(src: torch.Tensor, cout: int, cin: int, ks: int, s_co: int, s_ci: int,
                 s_k: Sequence[int], tbase: Sequence[int], tstep: Sequence[int], dtype,
                 cinp: Optional[int] = None, coutp: Optional[int] = None, s2d_mode: int = 0,
-                s2d_cp: int = 0, reuse: Optional[torch.Tensor] = None, q_amax: Optional[torch.Tensor] = None
-                ) -> Tuple[torch.Tensor, int, int]:
+                s2d_cp: int = 0, reuse: Optional[torch.Tensor] = None, q_amax: Optional[torch.Tensor] = None,
+                src_offset: int = 0) -> Tuple[torch.Tensor, int, int]:
     """Returns (packed [cinp/16][ks^3][coutp][16], coutp, cinp).  `reuse`: re-pack in place into an
     earlier result (keeps the buffer address stable: required for hipGraph replays).
     dtype ops.FP8: e4m3 bytes of w * 224 / q_amax[0] (q_amax: device f32[1], see amax_f32)."""
@@ -163,7 +163,8 @@ def weight_pack(src: torch.Tensor, cout: int, cin: int, ks: int, s_co: int, s_ci
     else:
         dst = torch.empty(shape, dtype=dtype, device=src.device)
     d = _lib.WpackDesc()
-    d.src, d.dst = src.data_ptr(), dst.data_ptr()
+    d.src, d.dst = src.data_ptr() + 4 * src_offset, dst.data_ptr()      # (src_offset: elements; a channel slice of the weight)
+    d._src_off = 4 * src_offset
     d.cout, d.cin, d.coutp, d.cinp, d.ks = cout, cin, coutp, cinp, ks
     d.s_co, d.s_ci = s_co, s_ci
     d.s_k = (C.c_int64 * 3)(*s_k)
@@ -219,8 +220,10 @@ def _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, st
     # marching k2 kernel only (PatchGAN on space-to-depth tensors): accumulator start values / f32 output
     d.y_f32 = 1 if (out.dtype == torch.float32 and x0.dtype != torch.float32) else 0
     if addend is not None:
-        assert addend.dtype == torch.float32 and addend.dim() == 5 and tuple(addend.shape[:4]) == (n, *grid) and addend.stride(4) == 1
+        assert addend.dtype == torch.float32 and addend.dim() == 5 and tuple(addend.shape[1:4]) == tuple(grid) and addend.stride(4) == 1
+        assert n % addend.shape[0] == 0 and addend.shape[4] >= coutp
         d.addend, d.ld_add = addend.data_ptr(), act_ld(addend)
+        d.add_n = addend.shape[0] if addend.shape[0] != n else 0      # grid sample i starts from addend sample i % add_n
     return d
 
 
@@ -229,6 +232,21 @@ def conv_num_tiles(x0, x1, wp, coutp, ks, stride, pad, out, grid, os=1, ooff=(0,
     tiles, tps = C.c_int32(0), C.c_int32(0)
     _lib.check(_lib.load().mi355_conv_num_tiles(C.byref(d), C.byref(tiles), C.byref(tps)), "conv_num_tiles")
     return tiles.value, tps.value
+
+
+def conv_k2_marches(n: int, s_extents, c_in: int, coutp: int) -> bool:
+    """Would a bf16 dense k2 (padding 0) convolution of an (n, *s_extents, c_in) space-to-depth tensor to coutp channels run
+    on conv_march2_kernel -- the plan that honours `addend` / an f32 output?  (Asked before a layer is split.)"""
+    d = _lib.ConvDesc()
+    d.x0, d.c0, d.ld0, d.n = 1, c_in, c_in, n                # (no launch: the planner only checks for non-null pointers)
+    d.di, d.hi, d.wi = s_extents
+    d.do_, d.ho, d.wo = (e - 1 for e in s_extents)
+    d.dy, d.hy, d.wy = d.do_, d.ho, d.wo
+    d.ks, d.stride, d.os = 2, 1, 1
+    d.wp, d.coutp, d.y, d.ldy, d.cstore = 1, coutp, 1, coutp, coutp
+    d.dtype = DT_BF16
+    pid = _lib.load().mi355_conv_plan_id(C.byref(d))
+    return pid > 0 and (pid % 10000) // 100 == 24          # 10000 ks + 1000 halo + 100 shape + ...: halo plan, shape 14
 
 
 # Optional launch probe (bench.py): called as probe(plan_id, desc, (cin, cout) real GEMM extents) and returns None or a callable
@@ -266,12 +284,16 @@ WGRAD_PROBE = None      # tests: called as probe(plan kind, desc) before a weigh
 
 
 def conv_wgrad(x0, x1, g, grid, gs, goff, ks, stride, pad, dw, cout, cin, s_co, s_ci, s_k, tbase, tstep,
-               accumulate=False, s2d_cp=0, g_cls_cout=0):
-    """dw (torch layout, f32) (+)= sum_p x[p*stride+tap-pad] * g[p*gs+goff]."""
+               accumulate=False, s2d_cp=0, g_cls_cout=0, dw_offset=0, n=None):
+    """dw (torch layout, f32) (+)= sum_p x[p*stride+tap-pad] * g[p*gs+goff].
+    dw_offset: element offset into dw (a channel slice of a layer's weight); n: samples of the grid when x0 holds fewer
+    (x sample = grid sample % x0.shape[0]: one input under several gradients)."""
     require_cuda(x0, x1, g, dw)
     assert dw.dtype == torch.float32 and g.dtype == x0.dtype
     d = _lib.WgradDesc()
-    n, di, hi, wi, c0 = x0.shape
+    xn, di, hi, wi, c0 = x0.shape
+    n = xn if n is None else n
+    d.xn = xn if n != xn else 0
     d.x0, d.c0, d.ld0 = x0.data_ptr(), c0, act_ld(x0)
     if x1 is not None:
         d.x1, d.c1, d.ld1 = x1.data_ptr(), x1.shape[4], act_ld(x1)
@@ -285,7 +307,7 @@ def conv_wgrad(x0, x1, g, grid, gs, goff, ks, stride, pad, dw, cout, cin, s_co, 
     d.goff = (C.c_int32 * 3)(*goff)
     d.ks, d.stride = ks, stride
     d.pad = (C.c_int32 * 3)(*pad)
-    d.dw, d.cout, d.cin = dw.data_ptr(), cout, cin
+    d.dw, d.cout, d.cin = dw.data_ptr() + 4 * dw_offset, cout, cin
     d.s_co, d.s_ci = s_co, s_ci
     d.s_k = (C.c_int64 * 3)(*s_k)
     d.tbase = (C.c_int32 * 3)(*tbase)
