@@ -240,6 +240,8 @@ def test_conv_fwd_bwd(hip, case, dtype):
         _ops().WGRAD_PROBE = None
     if (name.startswith("k3_ru") or name.startswith("k3_march")) and dtype == torch.bfloat16:
         assert kinds == [2], kinds                                       # wgrad_march_kernel (3x3x3, W >= 32, D >= 8)
+    if name.startswith("k1_pointwise") and dtype == torch.bfloat16:
+        assert kinds == [3], kinds                                       # wgrad_pw_kernel (1x1x1, <= 32 channels either side, >= 128 K voxels)
     off = 0
     for a, c in zip(acts, cins):
         close(from_act(a.grad, c), xcat.grad[:, off:off + c], dtype, "dx")

@@ -119,6 +119,32 @@ def bench_wgrad(dtype, reps, only=None):
                                            cin * 27, 27, (9, 3, 1), (0, 0, 0), (1, 1, 1)), reps)
         fl = 2.0 * cin * cout * 27 * s ** 3
         print(f"wgrad     {name:28s} {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TFLOP/s")
+    # the layers outside the 3x3x3 families: 1x1x1 head / final at full resolution (HBM streams), the PatchGAN's first blocks
+    # as dense k2 on space-to-depth operands (first block: its x- and y-parts, Fn.SplitS2dConvFn)
+    for name, cin, cout, s in [("k1 head 24->24 @128^3", 24, 24, 128), ("k1 final 32->6 @128^3", 32, 6, 128)]:
+        if only and only not in name:
+            continue
+        x = torch.randn(1, s, s, s, ops.round_up(cin, 16), device=DEV).to(dtype)
+        g = torch.randn(1, s, s, s, ops.round_up(cout, 16), device=DEV).to(dtype)
+        dw = torch.empty(cout, cin, 1, 1, 1, device=DEV)
+        kinds = []
+        ops.WGRAD_PROBE = lambda k, d: kinds.append(k)
+        ms = timeit(lambda: ops.conv_wgrad(x, None, g, (s, s, s), 1, (0, 0, 0), 1, 1, (0, 0, 0), dw, cout, cin, cin, 1, (1, 1, 1), (0, 0, 0), (1, 1, 1)), reps)
+        ops.WGRAD_PROBE = None
+        nb = (x.numel() + g.numel()) * x.element_size()
+        print(f"wgrad     {name:28s} {ms*1e3:9.1f} us  {nb/ms/1e6:8.1f} GB/s of operands   kind {kinds[0]}")
+    for name, n, cin, cp, cout, s in [("k2/s2d d1 x-part 24->32 @64^3", 1, 24, 32, 32, 64), ("k2/s2d d1 y-part 6->32 N=2", 2, 6, 8, 32, 64),
+                                      ("k2/s2d d2 32->64 @32^3 N=2", 2, 32, 32, 64, 32)]:
+        if only and only not in name:
+            continue
+        x = torch.randn(n, s + 1, s + 1, s + 1, 8 * cp, device=DEV).to(dtype)
+        g = torch.randn(n, s, s, s, ops.round_up(cout, 16), device=DEV).to(dtype)
+        dw = torch.empty(cout, cin, 4, 4, 4, device=DEV)
+        ms = timeit(lambda: ops.conv_wgrad(x, None, g, (s, s, s), 1, (0, 0, 0), 2, 1, (0, 0, 0), dw, cout, cin, cin * 64, 64, (16, 4, 1),
+                                           (0, 0, 0), (2, 2, 2), s2d_cp=cp), reps)
+        fl = 2.0 * 8 * cp * 8 * cout * n * s ** 3
+        nb = (x.numel() + g.numel()) * x.element_size()
+        print(f"wgrad     {name:30s} {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TFLOP/s (dense)  {nb/ms/1e6:8.1f} GB/s of operands")
 
 
 def bench_norm(dtype, reps, only=None):

@@ -757,9 +757,82 @@ __global__ __launch_bounds__(256, 2) void wgrad_deconv_kernel(const WgradArgs a,
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// wgrad_pw_kernel: weight gradient of the full-resolution 1x1x1 convolutions with <= 32 channels either side (generator
+// head 24 -> 24, src/model.py:21; final_conv 32 -> 6, MONAI BasicUNet at :22-28): D[ci][co] = sum_v x[v][ci] g[v][co] over
+// ~2 M voxels -- 64 + 32..64 bytes per voxel for 2 K FLOP, a pure HBM stream.  wgrad_bf16_kernel<1, ...> staged 256-voxel
+// tiles through registers with two barriers per tile and 4 MFMAs per wave between them: 64 - 73 us for 200 - 270 MB
+// (0.4 - 0.5 of the HBM roof).  Here every WAVE streams its own 64-voxel pieces: x and g rows (4 KB + 4 KB)
+// arrive by LDS-DMA in a wave-private ring of three stages (two in flight), are read back transposed
+// (ds_read_b64_tr_b16) and feed 4 MFMAs; no workgroup barrier in the loop, counted waits (the copies are inline assembly).
+// One workgroup per CU (96 KB of LDS): 64 KB of loads in flight per CU.  One f32 slab per workgroup (its 4 waves are
+// added through LDS in wave order), reduced by wgrad_reduce_kernel in slab order: deterministic.
+constexpr int kPwStages = 3, kPwStageB = 8192, kPwLds = 4 * kPwStages * kPwStageB;
+
+__global__ __launch_bounds__(256, 1) void wgrad_pw_kernel(const WgradArgs a, const long long nvox, const int nstage) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  char* const ring = smem + wave * (kPwStages * kPwStageB);
+  const dma_rsrc_t rsx = dma_rsrc(a.x0, ((nvox - 1) * a.ld0 + a.c0) * 2), rsg = dma_rsrc(a.g, ((nvox - 1) * a.ldg + a.cg) * 2);
+  // lane = (voxel of a 16-voxel instruction, 16-byte piece); channels past the tensor's width: zeros
+  const int piece = lane & 3, lv = lane >> 2;
+  const bool xok = piece * 8 < a.c0, gok = piece * 8 < a.cg;
+  const int xlane = (lv * a.ld0 + piece * 8) * 2, glane = (lv * a.ldg + piece * 8) * 2;
+  const int gi = lane & 15;
+  const int lane_off = (8 * h + (gi >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (gi & 3)) * 2;       // frag_tr's lane pattern
+  const int nw = gridDim.x * 4, first = blockIdx.x * 4 + wave;       // stage s of this wave = voxels [64 (first + s nw), + 64)
+  auto issue = [&](int s, int slot) __attribute__((always_inline)) {
+    const long long v0 = (long long)(first + (long long)s * nw) * 64;
+    const bool in = s >= 0 && v0 < nvox;                              // (past the end: zero fills, same instruction count)
+    char* dst = ring + slot * kPwStageB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long vb = v0 + i * 16;
+      const bool ok = in && vb + lv < nvox;
+      dma_lds_b128(rsx, dst + i * 1024, (ok && xok) ? (int)(vb * a.ld0 * 2) + xlane : (int)0x80000000, 0);
+      dma_lds_b128(rsg, dst + 4096 + i * 1024, (ok && gok) ? (int)(vb * a.ldg * 2) + glane : (int)0x80000000, 0);
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  const int mine = first < nstage ? (nstage - first + nw - 1) / nw : 0;     // stages of this wave
+  issue(0, 0);
+  issue(1, 1);
+  for (int s = 0; s < mine; ++s) {
+    issue(s + 2, (s + 2) % kPwStages);                                       // (slot of stage s - 1: its reads fed MFMAs already issued)
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                        // all but the two youngest stages (8 copies each) have landed
+    __builtin_amdgcn_sched_barrier(0);
+    const char* st = ring + (s % kPwStages) * kPwStageB + lane_off;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bf16x8 af = frag_tr(st + k * 1024), bfg = frag_tr(st + 4096 + k * 1024);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfg, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  dma_wait_all();
+  __syncthreads();
+  float* park = reinterpret_cast<float*>(smem);                              // [wave][j][lane]
+#pragma unroll
+  for (int j = 0; j < 16; ++j) park[(wave * 16 + j) * 64 + lane] = acc[j];
+  __syncthreads();
+  if (wave == 0) {
+    float* sl = a.slab + (long long)blockIdx.x * a.cinp * a.coutp;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float v = park[j * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) v += park[(w * 16 + j) * 64 + lane];
+      sl[(long long)acc_row(j, h) * a.coutp + r] = v;
+    }
+  }
+}
+
 struct WPlan { int ks, tpw, tap_groups, ci_tiles, co_tiles, splits, cinp32, coutp32; long long rows;
                bool fast, deconv4; int shape, tiles_d, tiles_h, tiles_w, ntiles, nslabs;
-               bool march; int seg_len, nseg; };
+               bool march; int seg_len, nseg; bool pw; };
 
 const int kWTD[2] = {2, 2}, kWTH[2] = {4, 8}, kWTW[2] = {32, 16};
 
@@ -825,6 +898,18 @@ int wplan(const mi355_wgrad_desc* d, WPlan* p) {
     p->splits = (int)sp;
     p->nslabs = d->ks == 1 ? p->splits * 4 : p->splits;
   }
+  // streaming 1x1x1 kernel: one (ci, co) tile, plain tensors on one grid, many voxels; 32-bit byte offsets
+  p->pw = false;
+  {
+    const long long nv = (long long)d->n * d->di * d->hi * d->wi;
+    if (p->fast && !cls && d->ks == 1 && d->c1 == 0 && d->c0 <= 32 && d->cg <= 32 && d->pad[0] == 0 && d->pad[1] == 0 && d->pad[2] == 0 &&
+        d->di == d->do_ && d->hi == d->ho && d->wi == d->wo && d->s2d_cp == 0 && d->xn == 0 && nv >= (1ll << 17) &&
+        nv * std::max(d->ld0, d->ldg) * 2 < (1ll << 31)) {
+      p->pw = true;
+      p->splits = 256;
+      p->nslabs = 256;
+    }
+  }
   // marching kernel: 3x3x3, padding 1, same extents, wide rows; 32-bit byte offsets
   p->march = false;
   if (p->fast && !cls && d->ks == 3 && d->pad[0] == 1 && d->pad[1] == 1 && d->pad[2] == 1 && d->di == d->do_ && d->hi == d->ho &&
@@ -872,7 +957,7 @@ extern "C" int64_t mi355_conv_wgrad_workspace(const mi355_wgrad_desc* d) {
 extern "C" int mi355_conv_wgrad_plan_kind(const mi355_wgrad_desc* d) {
   WPlan p;
   if (wplan(d, &p)) return -1;
-  return p.march ? 2 : (p.fast ? 1 : 0);
+  return p.march ? 2 : (p.pw ? 3 : (p.fast ? 1 : 0));
 }
 
 extern "C" int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream) {
@@ -899,7 +984,12 @@ extern "C" int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream) {
   a.g_cls_cout = d->g_cls_cout;
   a.xn = d->xn > 0 ? d->xn : d->n;
   MI355_REQUIRE(a.xn == d->n || (!p.march && !(p.fast && p.deconv4)), "wgrad: xn is not supported by this plan");
-  if (p.march) {
+  if (p.pw) {
+    const long long nv = (long long)d->n * d->di * d->hi * d->wi;
+    static const int attr = (int)hipFuncSetAttribute((const void*)wgrad_pw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPwLds);
+    if (attr) { mi355_set_error("wgrad_pw: cannot raise the dynamic LDS limit to %d bytes (hip error %d)", kPwLds, attr); return MI355_ERR_HIP; }
+    wgrad_pw_kernel<<<dim3(256), dim3(256), kPwLds, st>>>(a, nv, (int)((nv + 63) / 64));
+  } else if (p.march) {
     const WMarchArgs m{p.seg_len, p.nseg, p.tiles_h, p.tiles_w, p.nslabs, p.ci_tiles, p.co_tiles};
     static const int attr = (int)hipFuncSetAttribute((const void*)wgrad_march_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWmLds);
     if (attr) { mi355_set_error("wgrad_march: cannot raise the dynamic LDS limit to %d bytes (hip error %d)", kWmLds, attr); return MI355_ERR_HIP; }
