@@ -154,6 +154,14 @@ typedef struct mi355_conv_desc {
    * between two launches without a rounding.  Plans that cannot honour either field fail with MI355_ERR_UNSUPPORTED. */
   const float* addend; int32_t ld_add; int32_t y_f32;
   int32_t add_n;                  /* samples held by addend: sample i of the grid starts from addend sample i % add_n (0 = n) */
+  /* d2s != 0 (depth-to-space; bf16, ks 2): the transpose of a Conv3d(k4, s2, p1) -- MONAI UpCat's up-branch as one
+   * ConvTranspose3d(k4, s2, p1) of the low-resolution tensor (mi355_upcat_compose packs the weights: coutp = 8 * co columns
+   * (class, channel)).  x0: [n][di][hi][wi][c0]; the grid (do_, ho, wo) must equal (di, hi, wi); y: the PLAIN tensor
+   * [n][2 do_][2 ho][2 wo][ldy] (dy = 2 do_ ...), cstore <= co channels; output class b writes voxel 2 j + b.  bias [co];
+   * addend (f32, or bf16 when add_bf16 != 0): [add_n or n][dy][hy][wy][ld_add]; delta: NULL or f32 [27][co], added to the
+   * accumulators of the voxels on the volume's border (class 9 cd + 3 ch + cw: 0 first / 1 interior / 2 last voxel);
+   * stats_part: [8 * tiles][2][co], rows (tile, class). */
+  int32_t d2s; const float* delta; int32_t add_bf16;
 } mi355_conv_desc;
 int mi355_conv_fwd(const mi355_conv_desc* d, void* stream);
 int64_t mi355_conv_workspace_bytes(const mi355_conv_desc* d);
@@ -162,6 +170,30 @@ int64_t mi355_conv_workspace_bytes(const mi355_conv_desc* d);
 int mi355_conv_plan_id(const mi355_conv_desc* d);
 /* number of spatial tiles (= rows of stats_part) and tiles per sample (0 if tiles span samples) */
 int mi355_conv_num_tiles(const mi355_conv_desc* d, int32_t* tiles, int32_t* tiles_per_sample);
+
+/* ------------------------------------------------------------------------------------------
+ * The up-branch of MONAI's UpCat (BasicUNet(upsample="deconv"), call site src/model.py:22-28) without the up-sampled tensor:
+ * ConvTranspose3d(cl -> cu, k2, s2) followed by the [:, ce:] part of Conv3d(ce + cu -> co, k3, p1) is ONE transposed
+ * convolution of the low-resolution tensor with the 4x4x4 kernel k4[cl][co][4][4][4] (csrc/upcat.hip; even extents).
+ *   mi355_upcat_compose: k4 from wd [cl][cu][2][2][2] and wc [co][ce + cu][3][3][3]; optionally its bf16 packing for
+ *     mi355_conv_fwd's d2s mode (wp_d2s: [cl / 16][8][8 co][16]), the bias vector the consumer adds (biasp [co] =
+ *     bc + the interior share of the transposed convolution's bias bd) and the corrections of the 27 border classes
+ *     (delta [27][co], class = 9 cd + 3 ch + cw with 0 first voxel / 1 interior / 2 last voxel per axis).
+ *   mi355_upcat_chain: dwd, dwc[:, ce:] (+ the bias-path term) and dbd from dk4 and the border sums of dz (esum [27][co],
+ *     mi355_border_sums); dwc is the FULL [co][ce + cu][27] tensor, only the [:, ce:] part is written.
+ *   mi355_border_sums: e[9 sd + 3 sh + sw][c] = sum of g over the region (per axis: 0 all / 1 first / 2 last voxel); the
+ *     region (0, 0, 0) is NOT computed (0: the sum of a normalisation's input gradient over the volume is zero).
+ *   mi355_s2d_repack: plain NDHWC activation -> its space-to-depth tensor (same element type), every slot written.
+ * ---------------------------------------------------------------------------------------- */
+int mi355_upcat_compose(const float* wd, const float* wc, const float* bd, const float* bc, int32_t cl, int32_t cu, int32_t ce,
+                        int32_t co, float* k4, void* wp_d2s, float* biasp, float* delta, void* stream);
+int mi355_upcat_chain(const float* dk4, const float* wd, const float* wc, const float* bd, const float* esum, int32_t cl, int32_t cu,
+                      int32_t ce, int32_t co, float* dwd, float* dwc, float* dbd, int32_t accumulate, void* stream);
+int64_t mi355_border_sums_workspace(int32_t n, int32_t d, int32_t c);
+int mi355_border_sums(const void* g, int32_t ld, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c, int32_t dtype, float* workspace,
+                      float* e, void* stream);
+int mi355_s2d_repack(const void* src, int32_t ld_src, void* dst, int32_t ld_dst, int32_t n, int32_t d, int32_t h, int32_t w,
+                     int32_t c, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Weight gradient (autograd of Conv3d / ConvTranspose3d weights).

@@ -738,3 +738,148 @@ def test_two_source_pack_equals_two_single_packs(hip, dtype):
     ops.pack_ncdhw_s2d(x, sa, 32, 0, 24); ops.pack_ncdhw_s2d(y, sa, 32, 24, 32)
     ops.pack2(x, y, sb, 0, 32, s2d_cblk=32)
     assert torch.equal(sa, sb)
+
+
+# ------------------------------------------------------------------ UpCat's up-branch as one transposed convolution (csrc/upcat.hip)
+def _compose_ref(wd, wc_up):
+    """k4[ci][co][4][4][4] = full correlation of the transposed convolution's 2x2x2 kernel with the 3x3x3 kernel of the
+    concatenated convolution's up-branch, summed over the intermediate channels: conv_transpose3d of wd (as a batch of
+    (cu, 2, 2, 2) images) with the spatially FLIPPED wc (t = a - k + 2  <=>  t = a + (2 - k))."""
+    return F.conv_transpose3d(wd, wc_up.flip(2, 3, 4).permute(1, 0, 2, 3, 4).contiguous())       # weight: (cu, co, 3, 3, 3)
+
+
+def test_upcat_compose_chain_and_border_sums_match_torch(hip):
+    """The small kernels of the fused up-branch against plain torch on the CPU: k4 and its depth-to-space packing, the bias
+    vector and the 27 border-class corrections, the border-region sums of a gradient, and the chain rule from dk4 back to
+    dW_d / dW_c[:, ce:] / db_d (autograd of the torch formula)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(31)
+    cl, cu, ce, co = 64, 48, 32, 32
+    wd = (torch.rand(cl, cu, 2, 2, 2, generator=g) - 0.5).requires_grad_(True)
+    wc = (torch.rand(co, ce + cu, 3, 3, 3, generator=g) - 0.5).requires_grad_(True)
+    bd = (torch.rand(cu, generator=g) - 0.5).requires_grad_(True)
+    bc = torch.rand(co, generator=g) - 0.5
+    k4_ref = _compose_ref(wd, wc[:, ce:])
+    k4, wp, biasp, delta = ops.upcat_compose(wd.detach().to(DEV), wc.detach().to(DEV), bd.detach().to(DEV), bc.to(DEV), ce)
+    torch.testing.assert_close(k4.cpu(), k4_ref.detach(), rtol=1e-5, atol=1e-5)
+    # packing: wp[ci >> 4][e][blk * co + o][ci & 15] = k4[ci][o][3 - b - 2 e] per axis
+    wpf = wp.float().cpu()
+    for blk in range(8):
+        for e in range(8):
+            t = [3 - ((blk >> s) & 1) - 2 * ((e >> s) & 1) for s in (2, 1, 0)]
+            ref = k4.cpu()[:, :, t[0], t[1], t[2]]                                          # [ci][o] (the kernel's own f32 values)
+            got = wpf[:, e, blk * co:(blk + 1) * co, :].permute(0, 2, 1).reshape(cl, co)    # [chunk][o][16] -> [ci][o]
+            torch.testing.assert_close(got, ref.to(torch.bfloat16).float(), rtol=0, atol=0)
+    # bias tables: z_up of a ZERO input is the bias term alone
+    d, h, w = 4, 6, 8
+    up0 = bd.detach().view(1, cu, 1, 1, 1).expand(1, cu, d, h, w)
+    zb = F.conv3d(up0, wc.detach()[:, ce:], bc, 1, 1)[0]                                    # [co][d][h][w]
+    cls = lambda i, n_: 0 if i == 0 else (2 if i == n_ - 1 else 1)
+    got = torch.empty_like(zb)
+    for i in range(d):
+        for j in range(h):
+            for k in range(w):
+                got[:, i, j, k] = biasp.cpu() + delta.cpu()[cls(i, d) * 9 + cls(j, h) * 3 + cls(k, w)]
+    torch.testing.assert_close(got, zb, rtol=1e-5, atol=1e-5)
+    # border sums of a gradient tensor
+    for dtype in (torch.float32, torch.bfloat16):
+        gz = q(torch.rand(2, co, 6, 10, 12, generator=g) - 0.5, dtype)
+        e = ops.border_sums(to_act(gz, dtype), co).cpu()
+        sel = lambda s_, n_: slice(None) if s_ == 0 else (slice(0, 1) if s_ == 1 else slice(n_ - 1, n_))
+        for sd in range(3):
+            for sh in range(3):
+                for sw in range(3):
+                    ref = gz[:, :, sel(sd, 6), sel(sh, 10), sel(sw, 12)].sum((0, 2, 3, 4)) if (sd or sh or sw) else torch.zeros(co)
+                    torch.testing.assert_close(e[sd * 9 + sh * 3 + sw], ref, rtol=1e-4, atol=1e-4)
+    # chain rule: loss = <dk4, k4> + the bias path <dz, bias term> with dz summed over border regions
+    dk4 = torch.rand(cl, co, 4, 4, 4, generator=g) - 0.5
+    gz = torch.rand(1, co, 6, 10, 12, generator=g) - 0.5
+    gz = gz - gz.mean((2, 3, 4), keepdim=True)                  # zero sum per channel, like a normalisation's input gradient
+    up0 = bd.view(1, cu, 1, 1, 1).expand(1, cu, 6, 10, 12)
+    loss = (dk4 * k4_ref).sum() + (F.conv3d(up0, wc[:, ce:], None, 1, 1) * gz).sum()
+    loss.backward()
+    esum = ops.border_sums(to_act(gz, torch.float32), co)
+    dwd = torch.zeros(cl, cu, 2, 2, 2, device=DEV)
+    dwc = torch.full((co, ce + cu, 3, 3, 3), 7.0, device=DEV)
+    dbd = torch.zeros(cu, device=DEV)
+    ops.upcat_chain(dk4.to(DEV), wd.detach().to(DEV), wc.detach().to(DEV), bd.detach().to(DEV), esum, ce, dwd, dwc, dbd, False)
+    torch.testing.assert_close(dwd.cpu(), wd.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dwc.cpu()[:, ce:], wc.grad[:, ce:], rtol=1e-4, atol=1e-4)
+    assert float((dwc.cpu()[:, :ce] - 7.0).abs().max()) == 0.0            # the skip part belongs to another launch
+    torch.testing.assert_close(dbd.cpu(), bd.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("n,ce,cl,cu,co,low", [(1, 32, 64, 64, 32, (24, 32, 64)), (2, 32, 64, 64, 32, (10, 24, 40)),
+                                                (1, 64, 128, 64, 64, (16, 16, 32))])
+def test_upcat_fused_up_branch_matches_torch(hip, n, ce, cl, cu, co, low):
+    """Fn.UpCatConvFn (bf16) -- ConvTranspose3d(k2, s2) + concatenation + Conv3d(k3, p1) of MONAI's UpCat (BasicUNet at
+    src/model.py:22-28) without the up-sampled tensor -- against the three torch ops on the CPU: z, the fused statistics,
+    every input and parameter gradient.  Shapes: upcat_1 (64 -> 64 up, 96 -> 32), two samples with ragged tiles, upcat_2."""
+    from unet_bssfp_amd import functional as Fn
+    from unet_bssfp_amd.nn import Conv3d, ConvTranspose3d
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(37)
+    torch.manual_seed(11)
+    deconv, conv = ConvTranspose3d(cl, cu), Conv3d(ce + cu, co, 3, 1, 1)
+    with torch.no_grad():
+        deconv.weight.copy_(q(deconv.weight, dtype)); conv.weight.copy_(q(conv.weight, dtype))
+        deconv.bias.mul_(4.0)                                        # a deconv bias that matters at the border
+    skip = tuple(2 * e for e in low)
+    x_e = q(torch.rand(n, ce, *skip, generator=g) - 0.3, dtype).requires_grad_(True)
+    x_l = q(torch.rand(n, cl, *low, generator=g) - 0.3, dtype).requires_grad_(True)
+    wd, bd = deconv.weight.detach().clone().requires_grad_(True), deconv.bias.detach().clone().requires_grad_(True)
+    wc, bc = conv.weight.detach().clone().requires_grad_(True), conv.bias.detach().clone().requires_grad_(True)
+    z_ref = F.conv3d(torch.cat([x_e, F.conv_transpose3d(x_l, wd, bd, 2)], 1), wc, bc, 1, 1)
+    gz = torch.rand(z_ref.shape, generator=g) - 0.5
+    gz = q(gz - gz.mean((2, 3, 4), keepdim=True), dtype)              # (zero channel sums up to bf16 rounding: a norm's input gradient)
+    z_ref.backward(gz)
+    deconv, conv = deconv.to(DEV), conv.to(DEV)
+    a_e, a_l = to_act(x_e.detach(), dtype).requires_grad_(True), to_act(x_l.detach(), dtype).requires_grad_(True)
+    tables = Fn.UpCatTables()
+    plans = []
+    _ops().CONV_PROBE = lambda pid, d, real: plans.append((pid, d.d2s, d.y_f32))
+    try:
+        z, part = Fn.UpCatConvFn.apply(a_e, a_l, deconv.weight, deconv.bias, conv.weight, conv.bias, conv.spec, tables, True)
+        # (a) the kernels: against the same arithmetic on the operands the launch reads -- the composite kernel k4 ROUNDED to
+        #     bf16 (a derived operand, like the unfused path's bf16 `up`): only summation order and the output rounding remain
+        k4q = tables.bufs[0].cpu().to(dtype).float()
+        xl2 = x_l.detach().clone().requires_grad_(True)
+        bias_term = F.conv3d(bd.detach().view(1, cu, 1, 1, 1).expand(1, cu, *skip), wc.detach()[:, ce:], bc.detach(), 1, 1)
+        p_skip = F.conv3d(x_e.detach(), wc.detach()[:, :ce], None, 1, 1)
+        f32_skip = any(p[2] for p in plans)             # the skip part travelled as f32 (conv_march_kernel) or rounded to bf16
+        assert f32_skip == (low == (24, 32, 64)), plans
+        z_q = (p_skip if f32_skip else q(p_skip, dtype)) + F.conv_transpose3d(xl2, k4q, None, 2, 1) + bias_term
+        if f32_skip:
+            close(from_act(z, co), z_q.detach(), dtype, "z (bf16 k4)")
+        else:
+            # the skip part was rounded to bf16 by ITS launch, whose f32 sums differ from the CPU's in the last bits: where they
+            # straddle a rounding boundary the two roundings are one bf16 ulp of the skip part apart
+            err = (from_act(z, co) - z_q.detach()).abs()
+            bound = 1e-2 * z_q.detach().abs() + 2e-3 * float(z_q.detach().std()) + 2.0 ** -8 * p_skip.abs()
+            assert bool((err <= bound).all()), float((err - bound).max())
+        # (b) the function: against the three torch ops in f32 -- the operand rounding of k4 (2^-9 relative per weight) is what
+        #     separates the two, as the rounding of `up` does in the unfused path
+        got = from_act(z, co)
+        assert float((got - z_ref.detach()).norm() / z_ref.detach().norm()) <= 3e-3
+        shift = tables.bufs[2].cpu()
+        zc = z_q.detach() - shift.view(1, -1, 1, 1, 1)
+        st = part.sum(0).cpu()
+        e0 = (st[0, :co] - zc.sum((0, 2, 3, 4))).abs()
+        assert bool((e0 <= 2e-3 * ((zc.numel() / co) * (zc * zc).sum((0, 2, 3, 4))).sqrt() + 1e-6).all()), e0.max()
+        close_f32_sum(st[1, :co], (zc * zc).sum((0, 2, 3, 4)), "sum (z - shift)^2")
+        z.backward(to_act(gz, dtype))
+    finally:
+        _ops().CONV_PROBE = None
+    assert sum(1 for p in plans if p[1]) == 1 and all((p[0] % 10000) // 100 == 24 for p in plans if p[1]), plans
+    close(from_act(a_e.grad, ce), x_e.grad, dtype, "dx_e")
+    z_q.backward(gz)
+    close(from_act(a_l.grad, cl), xl2.grad, dtype, "dx_low (bf16 k4)")
+    assert float((from_act(a_l.grad, cl) - x_l.grad).norm() / x_l.grad.norm()) <= 3e-3
+    close_f32_sum(conv.weight.grad.cpu(), wc.grad, "dW_c")
+    close_f32_sum(deconv.weight.grad.cpu(), wd.grad, "dW_d")
+    # db_d lives on the border shell only (the interior cancels exactly behind a normalisation): compare on the scale of the
+    # shell's contribution, with the volume sum the reference also carries (bf16 rounding noise of gz) taken out
+    gsum = gz.sum((0, 2, 3, 4))
+    bd_ref = bd.grad - torch.einsum("ock,o->c", wc.detach()[:, ce:].reshape(co, cu, 27), gsum)
+    close_f32_sum(deconv.bias.grad.cpu(), bd_ref, "db_d")
+    assert float(conv.bias.grad.abs().max()) == 0.0

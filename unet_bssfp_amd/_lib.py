@@ -33,7 +33,8 @@ class ConvDesc(C.Structure):
                 ("y", _vp), ("ldy", _i32), ("cstore", _i32), ("dy", _i32), ("hy", _i32), ("wy", _i32),
                 ("os", _i32), ("ooff", _i32 * 3), ("stats_part", _vp), ("dtype", _i32),
                 ("workspace", _vp), ("workspace_bytes", _i64), ("cls_cout", _i32), ("nbias", _i32),
-                ("q_amax_x", _vp), ("q_amax_w", _vp), ("addend", _vp), ("ld_add", _i32), ("y_f32", _i32), ("add_n", _i32)]
+                ("q_amax_x", _vp), ("q_amax_w", _vp), ("addend", _vp), ("ld_add", _i32), ("y_f32", _i32), ("add_n", _i32),
+                ("d2s", _i32), ("delta", _vp), ("add_bf16", _i32)]
 
 
 class WgradDesc(C.Structure):
@@ -74,6 +75,11 @@ _SIGNATURES = {
     "mi355_unpack_ncdhw_s2d": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mi355_pack2_ncdhw": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mi355_pack2_ncdhw_s2d": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mi355_upcat_compose": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "mi355_upcat_chain": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "mi355_border_sums_workspace": (_i64, [_i32, _i32, _i32]),
+    "mi355_border_sums": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "mi355_s2d_repack": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mi355_weight_pack": (C.c_int, [C.POINTER(WpackDesc), _vp]),
     "mi355_weight_pack_multi": (C.c_int, [C.POINTER(WpackDesc), _i32, _vp]),
     "mi355_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), _vp]),

@@ -111,7 +111,33 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
     // tile padding.  Cost per workgroup and 32-channel group: (len + 1) input planes of fixed overhead + len output planes
     // of 2 x 4 x 2 ROWS MFMAs.
     bool march2 = false;
-    {
+    if (d->d2s) {
+      const long long nvi = (long long)d->n * d->di * d->hi * d->wi, nvo = (long long)d->n * d->dy * d->hy * d->wy;
+      MI355_REQUIRE(d->dtype == MI355_DT_BF16 && d->ks == 2 && d->c0 % 32 == 0 && d->c1 == 0 && d->os == 1 && d->coutp % 256 == 0 &&
+                        d->ooff[0] == 0 && d->ooff[1] == 0 && d->ooff[2] == 0 && d->pad[0] == 0 && d->pad[1] == 0 && d->pad[2] == 0 &&
+                        d->do_ == d->di && d->ho == d->hi && d->wo == d->wi && d->dy == 2 * d->do_ && d->hy == 2 * d->ho && d->wy == 2 * d->wo &&
+                        d->cstore <= d->coutp / 8 && (d->cstore & 7) == 0 && !d->y_f32 && d->add_n >= 0,
+                    "conv: bad depth-to-space descriptor");
+      MI355_REQUIRE(nvi * d->ld0 * 2 < (1ll << 31) && nvo * d->ldy * 2 < (1ll << 31) && (!d->addend || nvo * d->ld_add * (d->add_bf16 ? 2 : 4) < (1ll << 31)),
+                    "conv: depth-to-space tensors exceed 32-bit byte offsets");
+      long long best = -1; int best_len = 0, best_rows = 0;
+      for (int rows = 4; rows >= 2; rows -= 2) {
+        const int th = ceil_div(d->ho, 4 * rows), tw = ceil_div(d->wo, 32);
+        const long long fp = (long long)d->n * th * tw * (d->coutp / 32);
+        for (int ns = 1; ns <= d->do_ && ns <= 64; ++ns) {
+          const int len = ceil_div(d->do_, ns), segs = ceil_div(d->do_, len);
+          if (fp * segs < 128 && ns < d->do_ && ns < 64) continue;
+          const long long rounds = (fp * segs + 255) / 256, cost = rounds * ((len + 1) * 500ll + (long long)len * 512 * rows);
+          if (best < 0 || cost < best) { best = cost; best_len = len; best_rows = rows; }
+        }
+      }
+      MI355_REQUIRE(best >= 0, "conv: no depth-to-space plan");
+      march2 = true;
+      p->shape = 14;
+      p->seg_len = best_len;
+      p->nseg = ceil_div(d->do_, best_len);
+      p->vt = best_rows;
+    } else {
       const int pd = d->pad[0];
       const long long nvi = (long long)d->n * d->di * d->hi * d->wi, nvo = (long long)d->n * d->dy * d->hy * d->wy;
       const bool ok = d->dtype == MI355_DT_BF16 && d->ks == 2 && d->c0 % 32 == 0 && d->c1 % 32 == 0 && d->os == 1 &&
@@ -144,7 +170,8 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
         }
       }
     }
-    MI355_REQUIRE(march2 || (!d->addend && !d->y_f32), "conv: addend / y_f32 need the marching k2 plan (bf16, ks 2, 32-channel groups, wide rows)");
+    MI355_REQUIRE(march2 || !d->addend, "conv: addend needs the marching k2 plan (bf16, ks 2, 32-channel groups, wide rows)");
+    MI355_REQUIRE(d->d2s || (!d->delta && !d->add_bf16), "conv: delta / add_bf16 belong to the depth-to-space mode");
     auto count = [&](int sh, int ct) {
       return (long long)ceil_div(d->do_, kTD[sh]) * ceil_div(d->ho, kTH[sh]) * ceil_div(d->wo, kTW[sh]) * d->n *
              (d->coutp / (32 * ct));
@@ -157,7 +184,7 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
         const int f = forced_shape();
         const long long nv = (long long)d->n * d->di * d->hi * d->wi;
         const bool ru_ok = nv * d->ld0 * 2 < (1ll << 31) && nv * (d->c1 ? d->ld1 : 0) * 2 < (1ll << 31) &&
-                           (long long)d->n * d->dy * d->hy * d->wy * d->ldy * 2 < (1ll << 31);                       // 32-bit byte offsets
+                           (long long)d->n * d->dy * d->hy * d->wy * d->ldy * (d->y_f32 ? 4 : 2) < (1ll << 31);      // 32-bit byte offsets
         const bool big = count(6, p->ct) >= 1024;
         const long long c9 = count(9, p->ct);
         int pick = (p->ct == 1 ? c9 >= 1024 : c9 >= 512) ? 9 : (big ? 6 : 0);
@@ -261,12 +288,17 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
     p->tiles_d = p->tiles_h = p->tiles_w = 0;
     p->shape = 0;
   }
-  MI355_REQUIRE(p->halo || (!d->addend && !d->y_f32), "conv: addend / y_f32 need the marching k2 plan");
+  MI355_REQUIRE(p->halo || (!d->addend && !d->y_f32 && !d->d2s), "conv: addend / y_f32 / d2s need the marching k2 plan");
+  // f32 output on bf16 operands: the marching k2 kernel, and the marching 3x3x3 kernel of the <= 32-input-channel layers
+  MI355_REQUIRE(!d->y_f32 || (p->halo && (p->shape == 14 || (p->shape == 10 && d->dtype == MI355_DT_BF16 && (d->cstore & 15) == 0 &&
+                                                                   !d->bias && !d->stats_part))),
+                "conv: y_f32 is implemented by the marching k2 kernel and by conv_march_kernel (bf16, <= 32 input channels)");
   MI355_REQUIRE(d->dtype != MI355_DT_FP8 || (p->halo && p->shape == 10),
                 "conv: the fp8 path covers 3x3x3 stride-1 layers with 32 input channels in one source and a plain output grid");
   MI355_REQUIRE(p->tiles < (1ll << 31), "conv: too many tiles");
   p->ksplit = 1; p->rpb = 0;
   p->stat_rows = p->tiles; p->stat_rows_per_sample = p->tiles_per_sample;
+  if (d->d2s) { p->stat_rows *= 8; p->stat_rows_per_sample *= 8; }     // one statistics row per (tile, output class)
   p->pointwise = !p->halo && d->dtype == MI355_DT_BF16 && !d->cls_cout && d->ks == 1 && d->stride == 1 && d->os == 1 && p->vt == 2 &&
                  (d->c0 + d->c1) / 16 <= 2 && d->c1 == 0 && d->coutp == 32 && d->ooff[0] == 0 && d->ooff[1] == 0 && d->ooff[2] == 0 &&
                  d->dy == d->do_ && d->hy == d->ho && d->wy == d->wo && d->pad[0] == 0 && d->pad[1] == 0 && d->pad[2] == 0;
@@ -379,11 +411,13 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
       } else if (p.shape == 10) {
         if constexpr (sizeof(T) == 2) {
           static const int once = [] {
-            return raise_lds((const void*)conv_march_kernel<false>, MarchCfg<false>::LDS) | raise_lds((const void*)conv_march_kernel<true>, MarchCfg<true>::LDS);
+            return raise_lds((const void*)conv_march_kernel<false>, MarchCfg<false>::LDS) | raise_lds((const void*)conv_march_kernel<true>, MarchCfg<true>::LDS) |
+                   raise_lds((const void*)conv_march_kernel<false, true>, MarchCfg<false>::LDS);
           }();
           if (once) { mi355_set_error("conv_march: cannot raise the dynamic LDS limit to %d bytes (hip error %d)", MarchCfg<false>::LDS, once); return MI355_ERR_HIP; }
           MarchArgs m{p.seg_len, p.nseg, p.tiles_h, p.tiles_w, d->q_amax_x, d->q_amax_w};
           if (d->dtype == MI355_DT_FP8) conv_march_kernel<true><<<grid, block, MarchCfg<true>::LDS, st>>>(a, m);
+          else if (d->y_f32) conv_march_kernel<false, true><<<grid, block, MarchCfg<false>::LDS, st>>>(a, m);
           else conv_march_kernel<false><<<grid, block, MarchCfg<false>::LDS, st>>>(a, m);
         }
       } else if (p.shape == 11) {
@@ -414,12 +448,16 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
     } else if (p.shape == 14) {
       if constexpr (sizeof(T) == 2) {
         static const int once = [] {
-          return raise_lds((const void*)conv_march2_kernel<4>, March2Cfg<4>::LDS) | raise_lds((const void*)conv_march2_kernel<2>, March2Cfg<2>::LDS);
+          return raise_lds((const void*)conv_march2_kernel<4, false>, March2Cfg<4>::LDS) | raise_lds((const void*)conv_march2_kernel<2, false>, March2Cfg<2>::LDS) |
+                 raise_lds((const void*)conv_march2_kernel<4, true>, March2Cfg<4>::LDS) | raise_lds((const void*)conv_march2_kernel<2, true>, March2Cfg<2>::LDS);
         }();
         if (once) { mi355_set_error("conv_march2: cannot raise the dynamic LDS limit to %d bytes (hip error %d)", March2Cfg<4>::LDS, once); return MI355_ERR_HIP; }
-        March2Args m{p.seg_len, p.nseg, p.tiles_h, p.tiles_w, d->addend, d->ld_add, d->y_f32, d->add_n};
-        if (p.vt == 4) conv_march2_kernel<4><<<grid, block, March2Cfg<4>::LDS, st>>>(a, m);
-        else conv_march2_kernel<2><<<grid, block, March2Cfg<2>::LDS, st>>>(a, m);
+        March2Args m{p.seg_len, p.nseg, p.tiles_h, p.tiles_w, d->addend, d->ld_add, d->y_f32, d->add_n, d->add_bf16, d->delta};
+        if (d->d2s) {
+          if (p.vt == 4) conv_march2_kernel<4, true><<<grid, block, March2Cfg<4>::LDS, st>>>(a, m);
+          else conv_march2_kernel<2, true><<<grid, block, March2Cfg<2>::LDS, st>>>(a, m);
+        } else if (p.vt == 4) conv_march2_kernel<4, false><<<grid, block, March2Cfg<4>::LDS, st>>>(a, m);
+        else conv_march2_kernel<2, false><<<grid, block, March2Cfg<2>::LDS, st>>>(a, m);
       }
     } else { HALO_KS(2) }
   } else if (sizeof(T) == 2 && p.pointwise) {

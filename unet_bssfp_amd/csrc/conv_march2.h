@@ -20,6 +20,12 @@
 //     computed ONCE per training step (x is the same in the generator phase and in both calls of the discriminator
 //     phase, src/model.py:172,184-186, and the discriminator's weights do not change in between) and enters the three
 //     y-part launches this way; `y_f32` writes that x-part as f32 (no rounding between the two halves of the sum).
+//   * D2S = true (depth-to-space): the TRANSPOSE of such a strided convolution -- the up-branch of MONAI's UpCat as one
+//     ConvTranspose3d(k4, s2, p1) of the low-resolution tensor (upcat.hip).  Output class b = (bd, bh, bw) (voxel 2 j + b
+//     of the plain output tensor) is a dense k2 convolution of the cells j - (1 - b) + e, e in {0, 1}: blockIdx.y = (class,
+//     32-channel tile), the paddings are 1 - b per axis, weights column (class, co); output AND addend (bf16 or f32: the
+//     skip part of the concatenated convolution, computed by another launch) use the plain tensor's addressing; the 26
+//     border classes of the volume get their bias correction (`delta`) added to the accumulators before the statistics.
 #pragma once
 #include <type_traits>
 #include "conv_marchg.h"
@@ -35,9 +41,9 @@ template <int ROWS> struct March2Cfg {
   static constexpr int LDS = 2 * PLANE + WSLOTS * WUNIT + MISC + NI * 1024;
 };
 
-struct March2Args { int seg_len, nseg, tiles_h, tiles_w; const float* addend; int ld_add; int y_f32; int add_n; };
+struct March2Args { int seg_len, nseg, tiles_h, tiles_w; const void* addend; int ld_add; int y_f32; int add_n; int add_bf16; const float* delta; };
 
-template <int ROWS>
+template <int ROWS, bool D2S>
 __global__ __launch_bounds__(256, 1) void conv_march2_kernel(const ConvArgs a, const March2Args m) {
   using Cfg = March2Cfg<ROWS>;
   constexpr int HC = Cfg::HC, NI = Cfg::NI, NWI = Cfg::NWI, VB = 64, FH = Cfg::FH, HY = ROWS + 1, NG = 4;
@@ -47,7 +53,13 @@ __global__ __launch_bounds__(256, 1) void conv_march2_kernel(const ConvArgs a, c
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const int co_base = blockIdx.y * 32;
+  const int co_base = blockIdx.y * 32;                                  // weight columns of this workgroup
+  // D2S: blockIdx.y = class * (Co / 32) + channel tile; Co = a.coutp / 8 channels per class
+  const int cpc = D2S ? a.coutp >> 3 : a.coutp, ctiles = cpc >> 5;
+  const int blk = D2S ? (int)blockIdx.y / ctiles : 0, cot = D2S ? (int)blockIdx.y - blk * ctiles : (int)blockIdx.y;
+  const int bd = blk >> 2, bh = (blk >> 1) & 1, bw = blk & 1;
+  const int pd = D2S ? 1 - bd : a.pd, ph = D2S ? 1 - bh : a.ph, pw = D2S ? 1 - bw : a.pw;
+  const int och = cot * 32;                                             // first stored / bias / statistics channel of this workgroup
   int tile;
   {
     const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
@@ -70,7 +82,7 @@ __global__ __launch_bounds__(256, 1) void conv_march2_kernel(const ConvArgs a, c
     const int id = i * 4 + wave, v = id * 16 + (lane >> 2);
     const int hy = v / HC, hx = v - hy * HC;
     const int q = (lane & 3) ^ ((hx >> 2) & 3);
-    const int gh = h0 - a.ph + hy, gw = w0 - a.pw + hx;
+    const int gh = h0 - ph + hy, gw = w0 - pw + hx;
     const bool ok = v < Cfg::VOX && gh >= 0 && gh < a.hi && gw >= 0 && gw < a.wi;
     vtab[i * 256] = ok ? (((gh * a.wi + gw) << 2) | q) : -1;
   }
@@ -104,8 +116,8 @@ __global__ __launch_bounds__(256, 1) void conv_march2_kernel(const ConvArgs a, c
   };
   // does block kd of input plane p run (its output plane lies inside the segment)?  kd = 1 -> plane p - 1 + pd, kd = 0 -> p + pd
   auto runs = [&](int p, int kd) __attribute__((always_inline)) {
-    const int q = p + a.pd - kd;
-    return q >= d0 && q < d1 && p <= d1 - a.pd;
+    const int q = p + pd - kd;
+    return q >= d0 && q < d1 && p <= d1 - pd;
   };
 
   int aoff[2][2];
@@ -117,32 +129,48 @@ __global__ __launch_bounds__(256, 1) void conv_march2_kernel(const ConvArgs a, c
   }
   const int wlane = lane * 16;
 
-  const int cch = co_base + 16 * h;
+  const int cch = och + 16 * h;                                         // this lane: output channels cch .. cch + 15 of voxel / cell w0 + r
   float s1[16], s2[16];
   float* const blds = reinterpret_cast<float*>(patch) + 512;
-  if (tid < 32) blds[tid] = (a.bias && co_base + tid < a.nbias) ? a.bias[co_base + tid] : 0.f;
+  if (tid < 32) blds[tid] = (a.bias && och + tid < a.nbias) ? a.bias[och + tid] : 0.f;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
   const bool vox_ok = w0 + r < a.wo;
-  const int esz = m.y_f32 ? 4 : 2;
+  const int esz = m.y_f32 ? 4 : 2, asz = m.add_bf16 ? 2 : 4;
   const bool st0 = vox_ok && cch + 8 <= a.cstore, st1 = vox_ok && cch + 16 <= a.cstore;
   const auto rsy = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (int)((((long long)a.n * a.dy * a.hy * a.wy - 1) * a.ldy + a.cstore) * esz), 0x00020000);
-  const int yrow = ((ROWS * wave) * a.wy + w0 + r) * a.ldy * esz + cch * esz;
-  // the addend: f32 [n][do][ho][wo][ld_add], this lane's 16 channels of voxel (q, h0 + ROWS wave + row, w0 + r)
+  // output voxel of cell (q, row, col): the cell itself, or (D2S) voxel 2 cell + b of the plain tensor
+  constexpr int OS = D2S ? 2 : 1;
+  const int yrow = ((OS * (ROWS * wave) + bh) * a.wy + OS * (w0 + r) + bw) * a.ldy * esz + cch * esz;
+  // the addend: [n][dy][hy][wy][ld_add] (the output's geometry), f32 or bf16; this lane's 16 channels
   const int nadd = m.add_n > 0 ? m.add_n : a.n, tna = tn % nadd;       // (one addend under several samples: Discriminator.forward_pair)
   const auto rsa = __builtin_amdgcn_make_buffer_rsrc((void*)m.addend, 0,
-                                                     m.addend ? (int)((((long long)nadd * a.do_ * a.ho * a.wo - 1) * m.ld_add + a.coutp) * 4) : 0, 0x00020000);
-  const int arow = ((ROWS * wave) * a.wo + w0 + r) * m.ld_add * 4 + cch * 4;
+                                                     m.addend ? (int)((((long long)nadd * a.dy * a.hy * a.wy - 1) * m.ld_add + cpc) * asz) : 0, 0x00020000);
+  const int arow = ((OS * (ROWS * wave) + bh) * a.wy + OS * (w0 + r) + bw) * m.ld_add * asz + cch * asz;
   typedef float f32x4v __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
   // (re)initialise row `row` of a set for the output plane q it starts next: the addend's values, or zeros
   auto init_row = [&](f32x16 (&s)[ROWS], int q, const int row) __attribute__((always_inline)) {
     const bool ok = m.addend != nullptr && q >= d0 && q < d1 && vox_ok && h0 + ROWS * wave + row < a.ho;
-    const int off = ok ? ((tna * a.do_ + q) * a.ho + h0) * a.wo * m.ld_add * 4 + arow + row * a.wo * m.ld_add * 4 : (int)0x80000000;
+    const int off = ok ? ((tna * a.dy + OS * q + bd) * a.hy + OS * h0) * a.wy * m.ld_add * asz + arow + OS * row * a.wy * m.ld_add * asz
+                       : (int)0x80000000;
     if (m.addend != nullptr) {
+      if (m.add_bf16) {
 #pragma unroll
-      for (int i4 = 0; i4 < 4; ++i4) {
-        const f32x4v v = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsa, off + i4 * 16, 0, 0));
-        s[row][4 * i4] = v.x; s[row][4 * i4 + 1] = v.y; s[row][4 * i4 + 2] = v.z; s[row][4 * i4 + 3] = v.w;
+        for (int i8 = 0; i8 < 2; ++i8) {
+          const u32x4v v = __builtin_bit_cast(u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsa, off + i8 * 16, 0, 0));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            s[row][8 * i8 + 2 * j] = __uint_as_float(v[j] << 16);
+            s[row][8 * i8 + 2 * j + 1] = __uint_as_float(v[j] & 0xffff0000u);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+          const f32x4v v = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsa, off + i4 * 16, 0, 0));
+          s[row][4 * i4] = v.x; s[row][4 * i4 + 1] = v.y; s[row][4 * i4 + 2] = v.z; s[row][4 * i4 + 3] = v.w;
+        }
       }
     } else {
 #pragma unroll
@@ -157,8 +185,24 @@ __global__ __launch_bounds__(256, 1) void conv_march2_kernel(const ConvArgs a, c
     const bool row_ok = q >= 0 && h0 + ROWS * wave + row < a.ho;        // wave-uniform
     const bool stat = vox_ok && row_ok;
     const float4* bp = reinterpret_cast<const float4*>(blds + 16 * h);
-    const int ybase = ((tn * a.dy + q) * a.hy + h0) * a.wy * a.ldy * esz;
-    const int off = ybase + yrow + row * a.wy * a.ldy * esz;
+    const int ybase = ((tn * a.dy + OS * q + bd) * a.hy + OS * h0) * a.wy * a.ldy * esz;
+    const int off = ybase + yrow + OS * row * a.wy * a.ldy * esz;
+    if constexpr (D2S) {
+      // voxels on the volume's border: the transposed convolution's bias reaches fewer taps there (upcat.hip): class-wise
+      // correction of the accumulators, ahead of the statistics
+      if (m.delta != nullptr && stat) {
+        const int vd = 2 * q + bd, vh = 2 * (h0 + ROWS * wave + row) + bh, vw = 2 * (w0 + r) + bw;
+        const int cls = (vd == 0 ? 0 : (vd == a.dy - 1 ? 2 : 1)) * 9 + (vh == 0 ? 0 : (vh == a.hy - 1 ? 2 : 1)) * 3 + (vw == 0 ? 0 : (vw == a.wy - 1 ? 2 : 1));
+        if (cls != 13) {
+          const float4* dp = reinterpret_cast<const float4*>(m.delta + cls * cpc + cch);
+#pragma unroll
+          for (int i4 = 0; i4 < 4; ++i4) {
+            const float4 dv = dp[i4];
+            s[row][4 * i4] += dv.x; s[row][4 * i4 + 1] += dv.y; s[row][4 * i4 + 2] += dv.z; s[row][4 * i4 + 3] += dv.w;
+          }
+        }
+      }
+    }
     if (m.y_f32) {
 #pragma unroll
       for (int i4 = 0; i4 < 4; ++i4) {
@@ -267,7 +311,7 @@ __global__ __launch_bounds__(256, 1) void conv_march2_kernel(const ConvArgs a, c
     constexpr bool LAST = decltype(last_tag)::value;
     const char* apl = smem + (u & 1) * Cfg::PLANE;
     const int gn = LAST ? 0 : g + 1, pn = LAST ? p + 1 : p;             // the next unit
-    const ActSrc nx = act_src(pn, pn <= d1 - a.pd ? gn : ng);          // (past the segment's last unit: zero-fills, same count)
+    const ActSrc nx = act_src(pn, pn <= d1 - pd ? gn : ng);          // (past the segment's last unit: zero-fills, same count)
     const int nslot = (u + 1) & 1;
     int e[NI];
 #pragma unroll
@@ -283,7 +327,7 @@ __global__ __launch_bounds__(256, 1) void conv_march2_kernel(const ConvArgs a, c
     dma_wait_but<NWI + NI>();
     mg_barrier();
     // kd = 0 (slot (b + 1) & 3); requests: the next unit's kd = 0 weights -> slot (b + 3) & 3
-    const int qd = p - 1 + a.pd;
+    const int qd = p - 1 + pd;
     block(do0, apl, wl + ((b + 1) & 3) * Cfg::WUNIT, fresh,
           [&](const int gi) __attribute__((always_inline)) { if constexpr (LAST) { if (gi < ROWS) epilogue_row(done, do1 ? qd : -1, qd + 2, gi); } },
           [&](const int gi) __attribute__((always_inline)) {
@@ -299,7 +343,7 @@ __global__ __launch_bounds__(256, 1) void conv_march2_kernel(const ConvArgs a, c
   };
 
   // prologue: first plane unit (input plane d0 - pd, group 0), the weights of its two blocks
-  const int p0 = d0 - a.pd;
+  const int p0 = d0 - pd;
   {
     const ActSrc q0 = act_src(p0, 0);
     int e[NI];
@@ -356,9 +400,10 @@ __global__ __launch_bounds__(256, 1) void conv_march2_kernel(const ConvArgs a, c
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) { t1 += red[(w * 2 + 0) * 32 + r]; t2 += red[(w * 2 + 1) * 32 + r]; }
-      float* p = a.stats + ((long long)tile * 2) * a.coutp;
-      p[co_base + r] = t1;
-      p[a.coutp + co_base + r] = t2;
+      // one row per workgroup: [tile][2][coutp]; D2S: [tile * 8 + class][2][channels per class]
+      float* p = a.stats + ((long long)(D2S ? tile * 8 + blk : tile) * 2) * cpc;
+      p[och + r] = t1;
+      p[cpc + och + r] = t2;
     }
   }
 }

@@ -135,6 +135,23 @@ __global__ __launch_bounds__(256) void unpack_kernel(const T* __restrict__ src, 
   for (int ch = 0; ch < c; ++ch) d[(long long)ch * v] = Elem<T>::load(srow + ch);
 }
 
+// plain NDHWC activation -> its space-to-depth tensor S(a) (same element type): thread = (voxel, 16-byte piece)
+template <typename T>
+__global__ __launch_bounds__(256) void s2d_repack_kernel(const T* __restrict__ src, int lds_, T* __restrict__ dst, int ldd, long long v, int pieces, S2D q) {
+  constexpr int EPV = Elem<T>::kPer16B;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long vox = idx / pieces;
+  const int piece = (int)(idx - vox * pieces);
+  const int n = blockIdx.y;
+  if (vox >= v) return;
+  const long long row = (long long)n * v + vox;
+  long long srow; int blk, border;
+  s2d_cell(q, row, srow, blk, border);
+  const uint4 val = *reinterpret_cast<const uint4*>(src + row * lds_ + piece * EPV);
+  *reinterpret_cast<uint4*>(dst + srow * ldd + (long long)blk * q.cblk + piece * EPV) = val;
+  s2d_zero_siblings<T>(dst, q, srow, blk, border, ldd, piece * EPV);
+}
+
 // ------------------------------------------------------------------ weight pack
 struct WpackArgs {
   const float* src; void* dst;
@@ -1180,6 +1197,22 @@ int mi355_unpack_ncdhw_s2d(const void* src, float* dst, int32_t n, int32_t c, in
   if (rc) return rc;
   MI355_REQUIRE(coff + c <= cblk, "unpack_s2d: channel window exceeds the block");
   return unpack_impl(src, dst, n, c, (int64_t)d * h * w, ld, coff, dtype, S2D{d, h, w, cblk}, stream);
+}
+
+int mi355_s2d_repack(const void* src, int32_t ld_src, void* dst, int32_t ld_dst, int32_t n, int32_t d, int32_t h, int32_t w,
+                     int32_t c, int32_t dtype, void* stream) {
+  int rc = check_s2d(d, h, w, c, ld_dst, "s2d_repack");
+  if (rc) return rc;
+  MI355_REQUIRE(src && dst && n > 0 && ld_src >= c, "s2d_repack: bad argument");
+  MI355_REQUIRE(dtype == MI355_DT_F32 || dtype == MI355_DT_BF16, "s2d_repack: bad dtype");
+  const int epv = dtype == MI355_DT_F32 ? 4 : 8, pieces = c / epv;
+  MI355_REQUIRE(ld_src % epv == 0 && ld_dst % epv == 0, "s2d_repack: rows must be 16-byte aligned");
+  const long long v = (long long)d * h * w;
+  const dim3 grid((unsigned)((v * pieces + 255) / 256), (unsigned)n);
+  const S2D q{d, h, w, c};
+  if (dtype == MI355_DT_F32) s2d_repack_kernel<float><<<grid, dim3(256), 0, (hipStream_t)stream>>>((const float*)src, ld_src, (float*)dst, ld_dst, v, pieces, q);
+  else s2d_repack_kernel<bf16_t><<<grid, dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst, v, pieces, q);
+  return mi355_check_launch("s2d_repack");
 }
 
 int mi355_weight_pack(const mi355_wpack_desc* d, void* stream) {

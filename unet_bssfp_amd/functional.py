@@ -75,6 +75,10 @@ def repack_weights(module: torch.nn.Module):
         ops.weight_pack_multi(descs)
     for e in entries:
         e[0] = LayerCache._tag(e[2])
+    for m in module.modules():
+        tables = getattr(m, "upcat_tables", None)
+        if isinstance(tables, UpCatTables):
+            tables.refresh()
 
 
 _ZEROS = {}
@@ -493,6 +497,19 @@ class ConvSpec:
             w.detach(), self.cin, self.cout, 2, k ** 3, self.cin * k ** 3, (k * k, k, 1), (2, 2, 2), (-2, -2, -2),
             dtype, cinp=cinp, coutp=8 * cp, s2d_mode=2, s2d_cp=cp, reuse=r))
 
+    # channel slice [c_off, c_off + c_n) of a stride-1 weight: forward and data-gradient packings (UpCatConvFn's skip part)
+    def w_fwd_part(self, w, dtype, cinp, c_off, c_n):
+        k = self.ks
+        return self.cache.get(("fwd_part", dtype, cinp, c_off, c_n), w, lambda r: ops.weight_pack(
+            w.detach(), self.cout, c_n, k, self.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (1, 1, 1),
+            dtype, cinp, reuse=r, src_offset=c_off * k ** 3))
+
+    def w_dgrad_s1_part(self, w, dtype, cinp, c_off, c_n):
+        k = self.ks
+        return self.cache.get(("dgrad_part", dtype, cinp, c_off, c_n), w, lambda r: ops.weight_pack(
+            w.detach(), c_n, self.cout, k, k ** 3, self.cin * k ** 3, (k * k, k, 1), (k - 1,) * 3, (-1,) * 3,
+            dtype, cinp, reuse=r, src_offset=c_off * k ** 3))
+
     # channel slice [c_off, c_off + c_n) of the k4 s2 p1 weight in the space-to-depth packings (the PatchGAN's first block
     # split into the parts of cat([x, y], 1): SplitS2dConvFn)
     def w_fwd_s2d_part(self, w, dtype, cp, c_off, c_n):
@@ -828,6 +845,140 @@ class SplitS2dConvFn(Function):
             else:
                 db = ops.colsum(dz)[: spec.cout].contiguous()
         return None, dsy, dw, db, None, None, None, None
+
+
+class UpCatTables:
+    """What UpCatConvFn derives from the weights of one UpCat block (csrc/upcat.hip): the composite 4x4x4 kernel k4, its packing for
+    the depth-to-space launch, the bias vector / border corrections, and k4's packing as the weight of the virtual
+    Conv3d(co -> cl, k4, s2, p1) whose forward is the up-branch's data gradient.  Rebuilt IN PLACE (stable addresses: hipGraph
+    replays) whenever one of the four parameters has changed (version counters / the optimiser epoch)."""
+
+    def __init__(self):
+        self.tag = None
+        self.bufs = None
+        self.wpk = None
+
+    def stale(self, wd, bd, wc, bc) -> bool:
+        return self.tag != tuple(LayerCache._tag(t) for t in (wd, wc, bd, bc) if t is not None)
+
+    def get(self, wd, bd, wc, bc, ce, dtype):
+        tag = tuple(LayerCache._tag(t) for t in (wd, wc, bd, bc) if t is not None)
+        if tag != self.tag:
+            self.bufs = ops.upcat_compose(wd.detach(), wc.detach(), bd.detach(), bc.detach() if bc is not None else None, ce, out=self.bufs)
+            k4 = self.bufs[0]
+            cl, co = k4.shape[:2]
+            self.wpk = ops.weight_pack(k4, cl, co, 2, co * 64, 64, (16, 4, 1), (0, 0, 0), (2, 2, 2), dtype, cinp=8 * co, s2d_mode=1,
+                                       s2d_cp=co, reuse=self.wpk[0] if self.wpk is not None else None)
+            self.tag = tag
+            self.args = (wd, bd, wc, bc, ce, dtype)
+        return self.bufs, self.wpk
+
+    def refresh(self):
+        """after an optimiser step (repack_weights): rebuild now, so that the next forward finds everything fresh"""
+        if self.tag is not None:
+            self.get(*self.args)
+
+
+class UpCatConvFn(Function):
+    """z = Conv3d(ce + cu -> co, k3, p1)(cat([x_e, ConvTranspose3d(cl -> cu, k2, s2)(x_low)], 1)) + b_c  -- MONAI UpCat's
+    upsample + concatenation + first convolution (BasicUNet at src/model.py:22-28) -- WITHOUT the up-sampled tensor: the two
+    linear maps of the up-branch compose to one transposed convolution with a 4x4x4 kernel on the low-resolution tensor
+    (csrc/upcat.hip: 8 taps instead of 27 per output voxel, `up` neither written nor read).  Launches:
+      forward   skip part  P = conv3(x_e; W_c[:, :ce])                              (the layer's usual kernel, no bias)
+                up part    z = convT4(x_low; K4) + P + biasp (+ border classes)     (conv_march2_kernel, depth-to-space mode)
+      backward  dx_e = conv3^T(dz; W_c[:, :ce]);  S(dz);  dx_low = Kconv(S(dz));  dW_c[:, :ce] (usual kernel);
+                dK4 = Kconv's weight gradient;  border sums of dz;  chain rule -> dW_d, dW_c[:, ce:], db_d.
+    Even extents (skip = 2 x low), bf16.  The sum P + up-part rounds P to bf16 once (as the unfused path rounded `up`)."""
+
+    @staticmethod
+    def forward(ctx, x_e, x_low, wd, bd, wc, bc, spec_c: ConvSpec, tables: UpCatTables, want_stats: bool):
+        x_e, x_low = ops.as_act(x_e), ops.as_act(x_low)
+        n, D, H, W, ce = x_e.shape
+        cl = x_low.shape[4]
+        co = spec_c.cout
+        assert tuple(x_low.shape[1:4]) == (D // 2, H // 2, W // 2) and wc.shape[1] == ce + wd.shape[1] and co % 32 == 0
+        dtype, dev = x_e.dtype, x_e.device
+        (k4, wp, biasp, delta), _ = tables.get(wd, bd, wc, bc, ce, dtype)
+        wps, coutp, _ = spec_c.w_fwd_part(wc, dtype, ce, 0, ce)
+        # the skip part travels as f32 where its kernel can write f32 (conv_march_kernel: <= 32 input channels), else as bf16
+        p_skip = torch.empty((n, D, H, W, co), dtype=torch.float32, device=dev)
+        if not ops.conv_plan_ok(x_e, None, wps, coutp, 3, 1, (1, 1, 1), p_skip, (D, H, W)):
+            p_skip = ops.new_act(n, D, H, W, co, dtype, dev)
+        ops.conv_fwd(x_e, None, wps, coutp, None, 3, 1, (1, 1, 1), p_skip, (D, H, W), real=(ce, co))
+        out = ops.new_act(n, D, H, W, co, dtype, dev)
+        grid = (D // 2, H // 2, W // 2)
+        part = None
+        if want_stats:
+            tiles, _ = ops.conv_num_tiles(x_low, None, wp, 8 * co, 2, 1, (0, 0, 0), out, grid, addend=p_skip, d2s=True)
+            part = torch.empty((tiles, 2, co), dtype=torch.float32, device=dev)
+        ops.conv_fwd(x_low, None, wp, 8 * co, biasp, 2, 1, (0, 0, 0), out, grid, stats=part, addend=p_skip, d2s=True, delta=delta,
+                     real=(cl, 8 * co))
+        ctx.save_for_backward(x_e, x_low, wd, wc, bd)
+        ctx.spec_c, ctx.tables = spec_c, tables
+        ctx.params = (wd, bd, wc, bc)
+        if part is None:
+            part = torch.empty((0,), dtype=torch.float32, device=dev)
+        ctx.mark_non_differentiable(part)
+        ctx.set_materialize_grads(False)
+        return out, part
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz, _dpart):
+        if dz is None:
+            return (None,) * 9
+        x_e, x_low, wd, wc, bd = ctx.saved_tensors
+        spec_c: ConvSpec = ctx.spec_c
+        dz = ops.as_act(dz)
+        n, D, H, W, ce = x_e.shape
+        cl, co = x_low.shape[4], spec_c.cout
+        cu = wd.shape[1]
+        dtype, dev = x_e.dtype, x_e.device
+        grid = (D // 2, H // 2, W // 2)
+        (k4, _, _, _), wpk = ctx.tables.get(wd, bd, wc, ctx.params[3], ce, dtype)
+        dx_e = dx_low = dwd = dbd = dwc = dbc = None
+        if ctx.needs_input_grad[0]:
+            wp, coutp, _ = spec_c.w_dgrad_s1_part(wc, dtype, dz.shape[4], 0, ce)
+            dx_e = ops.new_act(n, D, H, W, ce, dtype, dev)
+            ops.conv_fwd(dz, None, wp, coutp, None, 3, 1, (1, 1, 1), dx_e, (D, H, W), real=(co, ce))
+        need_w = ctx.needs_input_grad[2] or ctx.needs_input_grad[4] or ctx.needs_input_grad[3]
+        sg = ops.s2d_repack(dz) if (ctx.needs_input_grad[1] or need_w) else None      # S(dz): Kconv's operand, forward and weight gradient
+        if ctx.needs_input_grad[1]:
+            dx_low = ops.new_act(n, *grid, cl, dtype, dev)
+            ops.conv_fwd(sg, None, wpk[0], wpk[1], None, 2, 1, (0, 0, 0), dx_low, grid, real=(co, cl))
+        if need_w:
+            wd_p, bd_p, wc_p, bc_p = ctx.params
+
+            def target(p):
+                sink = sink_of(p)
+                if sink is not None:
+                    return sink, sink_grad(p), not sink.fresh(p)
+                return None, torch.empty_like(p, dtype=torch.float32), False
+            sk_c, dwc_t, acc_c = target(wc_p)
+            sk_d, dwd_t, acc_d = target(wd_p)
+            sk_b, dbd_t, acc_b = target(bd_p)
+            assert acc_c == acc_d == acc_b, "the UpCat block's parameters are used together"
+            ops.conv_wgrad(x_e, None, dz, (D, H, W), 1, (0, 0, 0), 3, 1, (1, 1, 1), dwc_t, co, ce, (ce + cu) * 27, 27, (9, 3, 1),
+                           (0, 0, 0), (1, 1, 1), accumulate=acc_c)
+            dk4 = torch.empty_like(k4)
+            ops.conv_wgrad(sg, None, x_low, grid, 1, (0, 0, 0), 2, 1, (0, 0, 0), dk4, cl, co, co * 64, 64, (16, 4, 1), (0, 0, 0), (2, 2, 2),
+                           s2d_cp=co)
+            esum = ops.border_sums(dz, co)
+            ops.upcat_chain(dk4, wd.detach(), wc.detach(), bd.detach(), esum, ce, dwd_t, dwc_t, dbd_t, acc_c)
+            for sk, p in ((sk_c, wc_p), (sk_d, wd_p), (sk_b, bd_p)):
+                if sk is not None:
+                    sk.written(p)
+            dwc = None if sk_c is not None else dwc_t
+            dwd = None if sk_d is not None else dwd_t
+            dbd = None if sk_b is not None else dbd_t
+            if bc_p is not None and ctx.needs_input_grad[5]:
+                # a normalisation follows: the mean subtraction cancels the convolution's bias, its gradient is exactly zero
+                bsink = sink_of(bc_p)
+                if bsink is not None:
+                    bsink.written(bc_p)
+                else:
+                    dbc = _cached_zeros(co, dev)
+        return dx_e, dx_low, dwd, dbd, dwc, dbc, None, None, None
 
 
 # ====================================================================================== norm + act

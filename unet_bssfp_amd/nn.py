@@ -353,13 +353,22 @@ class Convolution(_Mi355Module):
         self.adn = _ADN(cout)
         self.cfg = Fn.NormCfg("instance", cout, eps=eps, slope=slope, p=float(dropout or 0.0))
 
-    def forward_act(self, x0, x1=None, feeds: Optional[Conv3d] = None):
-        """feeds: the convolution that consumes the result (fp8 mode: the norm kernel writes its e4m3 operand as well)"""
+    def forward_act(self, x0, x1=None, feeds: Optional[Conv3d] = None, up_from=None):
+        """feeds: the convolution that consumes the result (fp8 mode: the norm kernel writes its e4m3 operand as well);
+        up_from = (x_low, deconv module, tables): the second source is ConvTranspose3d(x_low), which is NOT materialised
+        (Fn.UpCatConvFn: the up-branch as one transposed 4x4x4 convolution of the low-resolution tensor)"""
         n, d, h, w = x0.shape[:4]
         cp = round_up(self.conv.out_channels, 16)
         # small levels (16^3, 8^3): the norm kernel computes the instance statistics itself, in one launch
         small = ops.norm_is_small(n, d, h, w, cp)
-        z, part = self.conv.forward_act(x0, x1, want_stats=not small, zero_bias_grad=True)
+        shift = self.conv.bias
+        if up_from is not None:
+            x_low, deconv, tables = up_from
+            z, part = Fn.UpCatConvFn.apply(x0, x_low, deconv.weight, deconv.bias, self.conv.weight, self.conv.bias, self.conv.spec,
+                                           tables, not small)
+            shift = tables.bufs[2]         # the statistics are those of z - (b_c + the interior share of the deconv bias)
+        else:
+            z, part = self.conv.forward_act(x0, x1, want_stats=not small, zero_bias_grad=True)
         emit8 = emit8_bwd = None
         if cp == 32 and z.dtype == torch.bfloat16 and Fn.Fp8Scales.producer_side:
             # BASELINE.json configs[4]: e4m3 operands come from the kernel that produces the bf16 tensor (delayed scaling)
@@ -369,7 +378,7 @@ class Convolution(_Mi355Module):
             if (self.conv.fp8 and torch.is_grad_enabled() and (x0.requires_grad or (x1 is not None and x1.requires_grad))
                     and ops.conv_fp8_layer_ok(n, d, h, w, cp, cin)):
                 emit8_bwd = self.conv.spec.fp8_slot("g", z.device)
-        return Fn.NormActFn.apply(z, part if not small else None, self.adn.N.weight, self.adn.N.bias, self.conv.bias, self.cfg,
+        return Fn.NormActFn.apply(z, part if not small else None, self.adn.N.weight, self.adn.N.bias, shift, self.cfg,
                                   self.training, None, None, False, None, small, 1, emit8, emit8_bwd)
 
 
@@ -379,8 +388,8 @@ class TwoConv(_Mi355Module):
         self.conv_0 = Convolution(cin, cout, dropout)
         self.conv_1 = Convolution(cout, cout, dropout)
 
-    def forward_act(self, x0, x1=None):
-        return self.conv_1.forward_act(self.conv_0.forward_act(x0, x1, feeds=self.conv_1.conv))
+    def forward_act(self, x0, x1=None, up_from=None):
+        return self.conv_1.forward_act(self.conv_0.forward_act(x0, x1, feeds=self.conv_1.conv, up_from=up_from))
 
 
 class Down(_Mi355Module):
@@ -410,7 +419,22 @@ class UpCat(_Mi355Module):
         self.upsample = _UpSample(cin, cup)
         self.convs = TwoConv(ccat + cup, cout, dropout)
 
+    fuse_up_branch = True      # bf16, even extents: ConvTranspose3d + concat + Conv3d without the up-sampled tensor (Fn.UpCatConvFn)
+
+    def _fused(self, x, x_e) -> bool:
+        deconv, conv = self.upsample.deconv, self.convs.conv_0.conv
+        co, cl = conv.out_channels, deconv.in_channels
+        return (self.fuse_up_branch and self.compute_dtype == torch.bfloat16 and x.dtype == torch.bfloat16
+                and tuple(x_e.shape[1:4]) == tuple(2 * e for e in x.shape[1:4])
+                and co in (32, 64) and cl % 32 == 0 and x.shape[4] == cl and x_e.shape[4] % 16 == 0
+                and x_e.shape[4] + deconv.out_channels == conv.in_channels and deconv.bias is not None
+                and x.shape[3] >= 32 and not ops.norm_is_small(x_e.shape[0], *x_e.shape[1:4], co))
+
     def forward_act(self, x, x_e):
+        if self._fused(x, x_e):
+            if not hasattr(self, "upcat_tables"):
+                self.upcat_tables = Fn.UpCatTables()
+            return self.convs.forward_act(x_e, None, up_from=(x, self.upsample.deconv, self.upcat_tables))
         x_0 = self.upsample.deconv.forward_act(x)
         if x_0.shape[1:4] != x_e.shape[1:4]:
             # MONAI UpCat (is_pad): a level whose extent is odd loses its last plane in MaxPool3d(2); the up-sampled map is

@@ -190,7 +190,8 @@ def weight_pack_multi(descs):
 
 
 # ------------------------------------------------------------------------------ convolution
-def _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, stats, cls_cout=0, fp8=None, addend=None):
+def _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, stats, cls_cout=0, fp8=None, addend=None,
+               d2s=False, delta=None):
     d = _lib.ConvDesc()
     n, di, hi, wi, c0 = x0.shape
     d.x0, d.c0, d.ld0 = x0.data_ptr(), c0, act_ld(x0)
@@ -219,19 +220,33 @@ def _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, st
     d.cls_cout = cls_cout
     # marching k2 kernel only (PatchGAN on space-to-depth tensors): accumulator start values / f32 output
     d.y_f32 = 1 if (out.dtype == torch.float32 and x0.dtype != torch.float32) else 0
+    if d2s:                                 # depth-to-space (transposed k4 s2 p1 convolution): `out` is the plain 2x tensor
+        d.d2s = 1
+        assert tuple(out.shape[1:4]) == tuple(2 * e for e in grid) and coutp % 256 == 0
+        d.delta = _ptr(delta)
     if addend is not None:
-        assert addend.dtype == torch.float32 and addend.dim() == 5 and tuple(addend.shape[1:4]) == tuple(grid) and addend.stride(4) == 1
-        assert n % addend.shape[0] == 0 and addend.shape[4] >= coutp
+        assert addend.dim() == 5 and tuple(addend.shape[1:4]) == tuple(out.shape[1:4]) and addend.stride(4) == 1
+        assert n % addend.shape[0] == 0 and addend.shape[4] >= (coutp // 8 if d2s else coutp)
+        if d2s and addend.dtype == torch.bfloat16:
+            d.add_bf16 = 1
+        else:
+            assert addend.dtype == torch.float32
         d.addend, d.ld_add = addend.data_ptr(), act_ld(addend)
         d.add_n = addend.shape[0] if addend.shape[0] != n else 0      # grid sample i starts from addend sample i % add_n
     return d
 
 
-def conv_num_tiles(x0, x1, wp, coutp, ks, stride, pad, out, grid, os=1, ooff=(0, 0, 0), fp8=None, addend=None) -> Tuple[int, int]:
-    d = _conv_desc(x0, x1, wp, coutp, None, ks, stride, pad, out, grid, os, ooff, None, 0, fp8, addend)
+def conv_num_tiles(x0, x1, wp, coutp, ks, stride, pad, out, grid, os=1, ooff=(0, 0, 0), fp8=None, addend=None, d2s=False) -> Tuple[int, int]:
+    d = _conv_desc(x0, x1, wp, coutp, None, ks, stride, pad, out, grid, os, ooff, None, 0, fp8, addend, d2s)
     tiles, tps = C.c_int32(0), C.c_int32(0)
     _lib.check(_lib.load().mi355_conv_num_tiles(C.byref(d), C.byref(tiles), C.byref(tps)), "conv_num_tiles")
     return tiles.value, tps.value
+
+
+def conv_plan_ok(x0, x1, wp, coutp, ks, stride, pad, out, grid) -> bool:
+    """Does mi355_conv_fwd have a plan for this launch (asked before choosing an f32 `out` on bf16 operands)?"""
+    d = _conv_desc(x0, x1, wp, coutp, None, ks, stride, pad, out, grid, 1, (0, 0, 0), None)
+    return _lib.load().mi355_conv_plan_id(C.byref(d)) > 0
 
 
 def conv_k2_marches(n: int, s_extents, c_in: int, coutp: int) -> bool:
@@ -255,17 +270,17 @@ CONV_PROBE = None
 
 
 def conv_fwd(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os=1, ooff=(0, 0, 0), stats=None, real=None,
-             cls_cout=0, fp8=None, addend=None):
+             cls_cout=0, fp8=None, addend=None, d2s=False, delta=None):
     """fp8 = (amax_x, amax_w): x0 and wp hold e4m3 bytes (cast_fp8 / weight_pack(dtype=FP8)), `out` is bf16.
     addend (f32, the output's geometry): z = conv(x) + addend + bias; an f32 `out` on bf16 operands keeps the sums unrounded
     (both: the marching k2 kernel, i.e. the PatchGAN's first block split into its x- and y-part)."""
-    require_cuda(x0, x1, wp, bias, out, stats, addend)
+    require_cuda(x0, x1, wp, bias, out, stats, addend, delta)
     if fp8 is None:
         assert (out.dtype == x0.dtype or out.dtype == torch.float32) and wp.dtype == x0.dtype
     else:
         assert x0.dtype == torch.uint8 and wp.dtype == torch.uint8 and out.dtype == torch.bfloat16 and x1 is None
     assert bias is None or (bias.dtype == torch.float32 and bias.is_contiguous())
-    d = _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, stats, cls_cout, fp8, addend)
+    d = _conv_desc(x0, x1, wp, coutp, bias, ks, stride, pad, out, grid, os, ooff, stats, cls_cout, fp8, addend, d2s, delta)
     lib = _lib.load()
     need = lib.mi355_conv_workspace_bytes(C.byref(d))
     if need < 0:
@@ -325,6 +340,59 @@ def conv_wgrad(x0, x1, g, grid, gs, goff, ks, stride, pad, dw, cout, cin, s_co, 
     ws = torch.empty((need // 4,), dtype=torch.float32, device=x0.device)
     d.workspace, d.workspace_bytes = ws.data_ptr(), need
     _lib.check(lib.mi355_conv_wgrad(C.byref(d), _stream()), "conv_wgrad")
+
+
+# ------------------------------------------------------------------------------ UpCat's up-branch as one transposed convolution
+def upcat_compose(wd: torch.Tensor, wc: torch.Tensor, bd: Optional[torch.Tensor], bc: Optional[torch.Tensor], ce: int, out=None):
+    """(k4 f32 [cl][co][4][4][4], its bf16 d2s packing [cl/16][8][8 co][16], biasp f32 [co], delta f32 [27][co]) from the
+    transposed convolution's weight wd [cl][cu][2][2][2] / bias bd and the concatenated convolution's weight wc
+    [co][ce + cu][3][3][3] / bias bc (csrc/upcat.hip).  out: an earlier result, overwritten in place (stable addresses)."""
+    require_cuda(wd, wc, bd, bc)
+    cl, cu = wd.shape[:2]
+    co = wc.shape[0]
+    assert wc.shape[1] == ce + cu and wd.is_contiguous() and wc.is_contiguous() and wd.dtype == wc.dtype == torch.float32
+    dev = wd.device
+    if out is None:
+        out = (torch.empty((cl, co, 4, 4, 4), dtype=torch.float32, device=dev),
+               torch.empty((cl // 16, 8, 8 * co, 16), dtype=torch.bfloat16, device=dev),
+               torch.empty((co,), dtype=torch.float32, device=dev), torch.empty((27, co), dtype=torch.float32, device=dev))
+    k4, wp, biasp, delta = out
+    _lib.check(_lib.load().mi355_upcat_compose(wd.data_ptr(), wc.data_ptr(), _ptr(bd), _ptr(bc), cl, cu, ce, co, k4.data_ptr(),
+                                               wp.data_ptr(), biasp.data_ptr() if bd is not None else None,
+                                               delta.data_ptr() if bd is not None else None, _stream()), "upcat_compose")
+    return out
+
+
+def upcat_chain(dk4, wd, wc, bd, esum, ce: int, dwd, dwc, dbd, accumulate: bool):
+    """dwd, dwc[:, ce:] and dbd (+)= the chain rule through k4 = compose(wd, wc) plus the bias-path terms from the border sums."""
+    require_cuda(dk4, wd, wc, bd, esum, dwd, dwc, dbd)
+    cl, cu = wd.shape[:2]
+    co = wc.shape[0]
+    assert dwc.is_contiguous() and dwc.shape == wc.shape and dwd.is_contiguous() and dk4.is_contiguous()
+    _lib.check(_lib.load().mi355_upcat_chain(dk4.data_ptr(), wd.data_ptr(), wc.data_ptr(), _ptr(bd), esum.data_ptr(), cl, cu, ce, co,
+                                             dwd.data_ptr(), dwc.data_ptr(), _ptr(dbd), 1 if accumulate else 0, _stream()), "upcat_chain")
+
+
+def border_sums(g: torch.Tensor, c: Optional[int] = None) -> torch.Tensor:
+    """e[27][c]: sums of the activation g over the 26 border regions of its volume (region (all, all, all): 0)."""
+    require_cuda(g)
+    n, d, h, w, cp = g.shape
+    c = cp if c is None else c
+    lib = _lib.load()
+    ws = torch.empty((lib.mi355_border_sums_workspace(n, d, c) // 4,), dtype=torch.float32, device=g.device)
+    e = torch.empty((27, c), dtype=torch.float32, device=g.device)
+    _lib.check(lib.mi355_border_sums(g.data_ptr(), act_ld(g), n, d, h, w, c, _DT[g.dtype], ws.data_ptr(), e.data_ptr(), _stream()), "border_sums")
+    return e
+
+
+def s2d_repack(x: torch.Tensor) -> torch.Tensor:
+    """plain activation (n, d, h, w, c) -> its space-to-depth tensor (n, d/2+1, h/2+1, w/2+1, 8c), same dtype."""
+    require_cuda(x)
+    n, d, h, w, c = x.shape
+    out = torch.empty(s2d_shape(n, d, h, w, c), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().mi355_s2d_repack(x.data_ptr(), act_ld(x), out.data_ptr(), act_ld(out), n, d, h, w, c, _DT[x.dtype], _stream()),
+               "s2d_repack")
+    return out
 
 
 # ------------------------------------------------------------------------------ fp8 operands
