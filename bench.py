@@ -50,7 +50,7 @@ import torch.distributed as dist  # noqa: E402
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "fp8": 5000.0}
 HBM_PEAK_GBS = 8000.0
 # plan id = 10000*ks + 1000*halo + 100*tile_shape + 10*voxel_subtiles_per_wave + cout_subtiles_per_wave
-PLAN_NAMES = {22441: "conv_march2_kernel<4>", 22421: "conv_march2_kernel<2>", 32041: "conv_march_kernel", 32141: "conv_marchg_kernel<4>", 32121: "conv_marchg_kernel<2>", 31941: "conv_ru_kernel<1>", 31942: "conv_ru_kernel<2>", 31021: "conv_halo_kernel<float,3,2,4,32,1>",
+PLAN_NAMES = {22421: "conv_march2_kernel", 32041: "conv_march_kernel", 32141: "conv_marchg_kernel<4>", 32121: "conv_marchg_kernel<2>", 31941: "conv_ru_kernel<1>", 31942: "conv_ru_kernel<2>", 31021: "conv_halo_kernel<float,3,2,4,32,1>",
               31022: "conv_halo_kernel<float,3,2,4,32,2>", 31411: "conv_halo_kernel<bf16_t,3,2,4,16,1,4>"}
 KERNEL_SOURCES = ("conv_march.h", "conv_marchg.h", "conv_march2.h", "conv_kernels.h", "conv_common.h", "conv_api.hip", "common.h")
 

@@ -196,7 +196,9 @@ def test_fp8_gan_step_at_config5_size_160(hip):
     # consumer chain; plus down_1.conv_0 (32 -> 64 at 80^3) -- and NO 3x3x3 layer with one 32-channel source ran in bf16
     assert sum(1 for p in e4m3 if p[4] == 160) >= 8, e4m3
     k3_c32 = [p for p in plans if p[0] // 10000 == 3 and p[2] == 32 and p[0] in (32041, 31941, 31942)]
-    assert len(e4m3) == len(k3_c32), (len(e4m3), len(k3_c32))
+    # (except the skip part of upcat_1's fused up-branch, Fn.UpCatConvFn: its 32 -> 32 partial convolution -- f32 output, two
+    #  generator passes -- and that part's data gradient stay on bf16 operands: three launches per step)
+    assert len(k3_c32) - len(e4m3) == 3, (len(e4m3), len(k3_c32))
     for k, ref in logs["bf16"].items():
         got = logs["fp8"][k]
         assert np.isfinite(got)

@@ -523,11 +523,11 @@ def test_s2d_layout_definition(hip, dtype):
     assert torch.equal(back, x)
 
 
-# bf16 plans of the wide cases: 22441 / 22421 = conv_march2_kernel<4> / <2> (the marching k2 kernel), forward and -- where the
-# (extent + 1)-wide space-to-depth gradient tiles well -- data gradient
+# bf16 plans of the wide cases: 22421 = conv_march2_kernel<2> (the marching k2 kernel: 8-row footprints, two workgroups per CU),
+# forward and -- where the (extent + 1)-wide space-to-depth gradient tiles well -- data gradient
 S2D_PLANS = {
-    (1, 30, 32, (32, 64, 128)): [22421, 21022],     # d1's widths: 8 groups of 32 S-channels, 8-row footprints, one-plane segments
-    (2, 30, 32, (64, 64, 128)): [22441, 21022],     # two samples (Discriminator.forward_pair), 16-row footprints, 2-plane segments
+    (1, 30, 32, (32, 64, 128)): [22421, 21022],     # d1's widths: 8 groups of 32 S-channels, one-plane segments
+    (2, 30, 32, (64, 64, 128)): [22421, 21022],     # two samples (Discriminator.forward_pair)
     (1, 30, 32, (40, 72, 96)): [22421, 22421],      # ragged in h (36 = 4.5 x 8) and w (48 = 1.5 x 32); gradient 21 x 37 x 49 marches
     (1, 32, 64, (32, 64, 64)): [22421, 21022],      # d2's widths: two output-channel blocks
     (1, 32, 32, (32, 62, 126)): [22421, 22421],     # gradient extents 17 x 32 x 64: the data gradient marches too (padding 1)

@@ -83,6 +83,34 @@ def bench_patchgan(dtype, reps, only=None):
         print(f"conv k2/s2d {name:26s} {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TFLOP/s (dense)  {nb/ms/1e6:7.1f} GB/s  plan {plan[0]}")
 
 
+def bench_upcat(dtype, reps, only=None):
+    """MONAI UpCat's upsample + concat + first convolution as Fn.UpCatConvFn (no up-sampled tensor) against the unfused launches"""
+    from unet_bssfp_amd import functional as Fn
+    from unet_bssfp_amd.nn import ConvTranspose3d
+    for name, ce, cl, cu, co, s in [("upcat_1 64->64 up, 96->32 @128^3", 32, 64, 64, 32, 64), ("upcat_2 128->64 up, 128->64 @64^3", 64, 128, 64, 64, 32)]:
+        if only and only not in name:
+            continue
+        deconv, conv = ConvTranspose3d(cl, cu).to(DEV), Conv3d(ce + cu, co, 3, 1, 1).to(DEV)
+        x_e = torch.randn(1, 2 * s, 2 * s, 2 * s, ce, device=DEV).to(dtype).requires_grad_(True)
+        x_l = torch.randn(1, s, s, s, cl, device=DEV).to(dtype).requires_grad_(True)
+        tables = Fn.UpCatTables()
+        fused = lambda: Fn.UpCatConvFn.apply(x_e, x_l, deconv.weight, deconv.bias, conv.weight, conv.bias, conv.spec, tables, True)[0]
+
+        def unfused():
+            up = Fn.ConvFn.apply(x_l, None, deconv.weight, deconv.bias, deconv.spec, False)[0]
+            return Fn.ConvFn.apply(x_e, up, conv.weight, conv.bias, conv.spec, True, True)[0]
+        for label, fn in (("fused", fused), ("unfused", unfused)):
+            with torch.no_grad():
+                ms_f = timeit(fn, reps)
+            z = fn()
+            g = torch.randn_like(z)
+            params = [deconv.weight, deconv.bias, conv.weight]
+            ms_b = timeit(lambda: torch.autograd.grad(z, [x_e, x_l] + params, g, retain_graph=True), reps)
+            print(f"upcat {label:8s} {name:36s} fwd {ms_f*1e3:8.1f} us   bwd {ms_b*1e3:8.1f} us")
+        ms = timeit(lambda: ops.upcat_compose(deconv.weight.detach(), conv.weight.detach(), deconv.bias.detach(), conv.bias.detach(), ce, out=tables.bufs), reps)
+        print(f"upcat compose  {name:36s}     {ms*1e3:8.1f} us")
+
+
 def bench_deconv(dtype, reps, only=None):
     """transposed conv k2 s2 (forward = one 1x1x1 GEMM with 8*Cout columns, data gradient = k2 s2 gather)"""
     from unet_bssfp_amd.nn import ConvTranspose3d
@@ -196,6 +224,8 @@ if __name__ == "__main__":
         bench_conv(dt, a.reps, a.only)
     if a.what in ("patchgan", "all"):
         bench_patchgan(dt, a.reps, a.only)
+    if a.what in ("upcat", "all"):
+        bench_upcat(dt, a.reps, a.only)
     if a.what in ("deconv", "all"):
         bench_deconv(dt, a.reps, a.only)
     if a.what in ("wgrad", "all"):

@@ -120,15 +120,17 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
                     "conv: bad depth-to-space descriptor");
       MI355_REQUIRE(nvi * d->ld0 * 2 < (1ll << 31) && nvo * d->ldy * 2 < (1ll << 31) && (!d->addend || nvo * d->ld_add * (d->add_bf16 ? 2 : 4) < (1ll << 31)),
                     "conv: depth-to-space tensors exceed 32-bit byte offsets");
-      long long best = -1; int best_len = 0, best_rows = 0;
-      for (int rows = 4; rows >= 2; rows -= 2) {
-        const int th = ceil_div(d->ho, 4 * rows), tw = ceil_div(d->wo, 32);
+      // 8-row footprints, two workgroups per CU (512 per round)
+      long long best = -1; int best_len = 0;
+      const int best_rows = 2;
+      {
+        const int th = ceil_div(d->ho, 8), tw = ceil_div(d->wo, 32);
         const long long fp = (long long)d->n * th * tw * (d->coutp / 32);
         for (int ns = 1; ns <= d->do_ && ns <= 64; ++ns) {
           const int len = ceil_div(d->do_, ns), segs = ceil_div(d->do_, len);
-          if (fp * segs < 128 && ns < d->do_ && ns < 64) continue;
-          const long long rounds = (fp * segs + 255) / 256, cost = rounds * ((len + 1) * 500ll + (long long)len * 512 * rows);
-          if (best < 0 || cost < best) { best = cost; best_len = len; best_rows = rows; }
+          if (fp * segs < 256 && ns < d->do_ && ns < 64) continue;
+          const long long rounds = (fp * segs + 511) / 512, cost = rounds * ((len + 1) * 500ll + (long long)len * 1024);
+          if (best < 0 || cost < best) { best = cost; best_len = len; }
         }
       }
       MI355_REQUIRE(best >= 0, "conv: no depth-to-space plan");
@@ -148,17 +150,20 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
                       nvo * d->ldy * (d->y_f32 ? 4 : 2) < (1ll << 31) && (!d->addend || nvo * d->ld_add * 4 < (1ll << 31)) && d->add_n >= 0 &&
                       forced_shape() != 0;
       if (ok) {
-        long long best = -1; int best_len = 0, best_rows = 0;
-        for (int rows = 4; rows >= 2; rows -= 2) {
-          const int th = ceil_div(d->ho, 4 * rows), tw = ceil_div(d->wo, 32);
+        // 8-row footprints, two workgroups per CU (512 per round); cost per workgroup and 32-channel group: (len + 1) input planes
+        // of fixed overhead + len output planes of 32 MFMAs per wave
+        long long best = -1; int best_len = 0;
+        const int best_rows = 2;
+        {
+          const int th = ceil_div(d->ho, 8), tw = ceil_div(d->wo, 32);
           // (rows x columns the tiles cover against the ones that exist: S-layout gradients are 2^k + 1 wide)
-          if ((long long)th * 4 * rows * tw * 32 * 2 > 3ll * d->ho * d->wo) continue;
+          const bool tiles_ok = (long long)th * 8 * tw * 32 * 2 <= 3ll * d->ho * d->wo;
           const long long fp = (long long)d->n * th * tw * (d->coutp / 32);
-          for (int ns = 1; ns <= d->do_ && ns <= 64; ++ns) {
+          for (int ns = 1; tiles_ok && ns <= d->do_ && ns <= 64; ++ns) {
             const int len = ceil_div(d->do_, ns), segs = ceil_div(d->do_, len);
             if (fp * segs < 128) continue;
-            const long long rounds = (fp * segs + 255) / 256, cost = rounds * ((len + 1) * 500ll + (long long)len * 512 * rows);
-            if (best < 0 || cost < best) { best = cost; best_len = len; best_rows = rows; }
+            const long long rounds = (fp * segs + 511) / 512, cost = rounds * ((len + 1) * 500ll + (long long)len * 1024);
+            if (best < 0 || cost < best) { best = cost; best_len = len; }
           }
         }
         if (best >= 0) {
@@ -448,15 +453,11 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
     } else if (p.shape == 14) {
       if constexpr (sizeof(T) == 2) {
         static const int once = [] {
-          return raise_lds((const void*)conv_march2_kernel<4, false>, March2Cfg<4>::LDS) | raise_lds((const void*)conv_march2_kernel<2, false>, March2Cfg<2>::LDS) |
-                 raise_lds((const void*)conv_march2_kernel<4, true>, March2Cfg<4>::LDS) | raise_lds((const void*)conv_march2_kernel<2, true>, March2Cfg<2>::LDS);
+          return raise_lds((const void*)conv_march2_kernel<2, false>, March2Cfg<2>::LDS) | raise_lds((const void*)conv_march2_kernel<2, true>, March2Cfg<2>::LDS);
         }();
-        if (once) { mi355_set_error("conv_march2: cannot raise the dynamic LDS limit to %d bytes (hip error %d)", March2Cfg<4>::LDS, once); return MI355_ERR_HIP; }
+        if (once) { mi355_set_error("conv_march2: cannot raise the dynamic LDS limit to %d bytes (hip error %d)", March2Cfg<2>::LDS, once); return MI355_ERR_HIP; }
         March2Args m{p.seg_len, p.nseg, p.tiles_h, p.tiles_w, d->addend, d->ld_add, d->y_f32, d->add_n, d->add_bf16, d->delta};
-        if (d->d2s) {
-          if (p.vt == 4) conv_march2_kernel<4, true><<<grid, block, March2Cfg<4>::LDS, st>>>(a, m);
-          else conv_march2_kernel<2, true><<<grid, block, March2Cfg<2>::LDS, st>>>(a, m);
-        } else if (p.vt == 4) conv_march2_kernel<4, false><<<grid, block, March2Cfg<4>::LDS, st>>>(a, m);
+        if (d->d2s) conv_march2_kernel<2, true><<<grid, block, March2Cfg<2>::LDS, st>>>(a, m);
         else conv_march2_kernel<2, false><<<grid, block, March2Cfg<2>::LDS, st>>>(a, m);
       }
     } else { HALO_KS(2) }

@@ -11,9 +11,11 @@
 //     it starts (p + pad); two accumulator sets (2 x ROWS x 16 registers) swap roles from plane to plane;
 //   * the weights of block (g, kd) -- 4 (kh, kw) taps x 2 chunks = 8 fragment blocks, 8 KB -- stream through a ring of four
 //     slots two blocks ahead; per fragment group (chunk, kw): 2 weight + ROWS + 1 activation fragments, 2 ROWS MFMAs;
-//   * counted waits as in conv_marchg.h (the copies are inline assembly the compiler does not track): all plane copies of
-//     the next unit are issued in the unit's first block, so that "everything but this block's two weight copies" at the
-//     end of the second block covers them;
+//   * a unit is only 16 ROWS MFMAs per wave: shorter than a loaded memory latency, and in-order counted waits cannot keep a
+//     copy in flight for longer than the next two blocks -- so the latency is hidden by OCCUPANCY instead: 8-row footprints
+//     (ROWS = 2), two workgroups per CU.  Counted waits as in conv_marchg.h (the copies are inline assembly the compiler does not
+//     track): all plane copies of the next unit are issued in the unit's first block, so that "everything but this block's
+//     two weight copies" at the end of the second block covers them;
 //   * ACCUMULATOR INIT FROM MEMORY (`addend`): a set that starts an output plane is loaded from an f32 tensor of the
 //     output's geometry instead of being zeroed -- z = conv(x) + addend + bias, with the fused statistics taken of
 //     conv(x) + addend.  The PatchGAN's first block is linear in its input cat([x, y]): the x-part of its convolution is
@@ -37,18 +39,23 @@ template <int ROWS> struct March2Cfg {
   static constexpr int PLANE = BLOCKS * 1024;
   static constexpr int WBLK = 8, NWI = WBLK / 4, WUNIT = WBLK * 1024; // weight slot: 2 chunks x 4 taps
   static constexpr int WSLOTS = 4;
-  static constexpr int MISC = 4096;
-  static constexpr int LDS = 2 * PLANE + WSLOTS * WUNIT + MISC + NI * 1024;
+  // plane units: the one being read + one in flight.  ROWS = 2: 79 KB of LDS and at most 256 registers -- TWO workgroups per CU,
+  // whose copy latencies and MFMA phases overlap each other (measured: d1 59 -> 48 us against 16-row footprints at one
+  // workgroup per CU; a third unit buffer with copies two units ahead changed nothing there)
+  static constexpr int ASLOTS = 2;
+  static constexpr int MISC = 2048;                                   // statistics scratch [256 floats], bias [32 floats]
+  static constexpr int LDS = ASLOTS * PLANE + WSLOTS * WUNIT + MISC + NI * 1024;
+  static_assert(ROWS != 2 || 2 * LDS <= 160 * 1024, "ROWS = 2: two workgroups per CU");
 };
 
 struct March2Args { int seg_len, nseg, tiles_h, tiles_w; const void* addend; int ld_add; int y_f32; int add_n; int add_bf16; const float* delta; };
 
 template <int ROWS, bool D2S>
-__global__ __launch_bounds__(256, 1) void conv_march2_kernel(const ConvArgs a, const March2Args m) {
+__global__ __launch_bounds__(256, ROWS == 2 ? 2 : 1) void conv_march2_kernel(const ConvArgs a, const March2Args m) {
   using Cfg = March2Cfg<ROWS>;
   constexpr int HC = Cfg::HC, NI = Cfg::NI, NWI = Cfg::NWI, VB = 64, FH = Cfg::FH, HY = ROWS + 1, NG = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const wl = smem + 2 * Cfg::PLANE;
+  char* const wl = smem + Cfg::ASLOTS * Cfg::PLANE;
   char* const patch = wl + Cfg::WSLOTS * Cfg::WUNIT;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(256, 1) void conv_march2_kernel(const ConvArgs a, c
 
   const int cch = och + 16 * h;                                         // this lane: output channels cch .. cch + 15 of voxel / cell w0 + r
   float s1[16], s2[16];
-  float* const blds = reinterpret_cast<float*>(patch) + 512;
+  float* const blds = reinterpret_cast<float*>(patch) + 256;
   if (tid < 32) blds[tid] = (a.bias && och + tid < a.nbias) ? a.bias[och + tid] : 0.f;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
@@ -288,31 +295,29 @@ __global__ __launch_bounds__(256, 1) void conv_march2_kernel(const ConvArgs a, c
       for (int gi = 0; gi < NG; ++gi) { within(gi); between(gi); }
     }
   };
-  // copy tickets of a block: nw weight copies and na plane copies, ticket t goes behind fragment group t * NG / nt
+  // copy tickets of a block: NWI weight copies, then na plane copies (the order matters for the counted waits); ticket t
+  // goes behind fragment group t * NG / nt
   auto tickets = [&](const int gi, const int na, auto wt, auto at) __attribute__((always_inline)) {
     const int nt = NWI + na;
 #pragma unroll
     for (int t = 0; t < NWI + NI; ++t) {
       if (t >= nt || (t * NG) / nt != gi) continue;
-      // weight copies first in their share of the order: W A A A A W A A A A A (na = NI) or W W (na = 0)
-      const int wpos0 = 0, wpos1 = na ? (nt / 2) : 1;
-      if (t == wpos0) wt(0);
-      else if (t == wpos1) wt(1);
-      else at(t - 1 - (t > wpos1 ? 1 : 0));
+      if (t < NWI) wt(t);
+      else at(t - NWI);
     }
   };
   static_assert(NWI == 2, "ticket order assumes two weight copies per wave and block");
 
-  int u = 0;                                                           // units done: act slot u & 1, blocks done 2 u
+  int u = 0, us = 0;                                                   // units done (blocks done 2 u); act slot of the current unit
   auto nothing = [&](const int) __attribute__((always_inline)) {};
   // unit (p, g): block kd = 1 on `done` (output plane p - 1 + pd), block kd = 0 on `fresh` (plane p + pd).  LAST (compile time):
   // the plane's last group -- `done` is complete after the kd = 1 block; its rows are converted / stored under the kd = 0 block.
   auto unit = [&](auto last_tag, int p, int g, f32x16 (&done)[ROWS], f32x16 (&fresh)[ROWS]) __attribute__((always_inline)) {
     constexpr bool LAST = decltype(last_tag)::value;
-    const char* apl = smem + (u & 1) * Cfg::PLANE;
+    const char* apl = smem + us * Cfg::PLANE;
     const int gn = LAST ? 0 : g + 1, pn = LAST ? p + 1 : p;             // the next unit
-    const ActSrc nx = act_src(pn, pn <= d1 - pd ? gn : ng);          // (past the segment's last unit: zero-fills, same count)
-    const int nslot = (u + 1) & 1;
+    const ActSrc nx = act_src(pn, pn <= d1 - pd ? gn : ng);           // (past the segment's last unit: zero-fills, same count)
+    const int nslot = us ^ 1;
     int e[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) e[i] = vtab[i * 256];
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(256, 1) void conv_march2_kernel(const ConvArgs a, c
       tickets(gi, NI, [&](const int i) __attribute__((always_inline)) { w_ticket(r1n, gn, 1, (b + 2) & 3, i); },
               [&](const int i) __attribute__((always_inline)) { act_ticket(nx, nslot, i, e[i]); });
     });
-    dma_wait_but<NWI + NI>();
+    dma_wait_but<NWI + NI>();                  // in flight: this block's copies; landed: everything older (this unit's kd = 0 weights)
     mg_barrier();
     // kd = 0 (slot (b + 1) & 3); requests: the next unit's kd = 0 weights -> slot (b + 3) & 3
     const int qd = p - 1 + pd;
@@ -336,13 +341,14 @@ __global__ __launch_bounds__(256, 1) void conv_march2_kernel(const ConvArgs a, c
     dma_wait_but<NWI>();                       // ... which stay in flight; everything older (the whole next plane unit) has landed
     mg_barrier();
     ++u;
+    us ^= 1;
   };
   auto plane = [&](int p, f32x16 (&done)[ROWS], f32x16 (&fresh)[ROWS]) __attribute__((always_inline)) {
     for (int g = 0; g + 1 < ng; ++g) unit(std::false_type{}, p, g, done, fresh);
     unit(std::true_type{}, p, ng - 1, done, fresh);
   };
 
-  // prologue: first plane unit (input plane d0 - pd, group 0), the weights of its two blocks
+  // prologue: the first plane unit (input plane d0 - pd, group 0), the weights of its two blocks
   const int p0 = d0 - pd;
   {
     const ActSrc q0 = act_src(p0, 0);

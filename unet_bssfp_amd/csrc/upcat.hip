@@ -29,133 +29,185 @@ __device__ __forceinline__ int t_of(int a, int k) {
   return td * 16 + th * 4 + tw;
 }
 
-// K4 and its packing for conv_march2_kernel's d2s mode: one thread per (ci, co, t)
-__global__ __launch_bounds__(256) void upcat_compose_kernel(const float* __restrict__ wd, const float* __restrict__ wc, int cl, int cu, int ce, int co,
-                                                            float* __restrict__ k4, bf16_t* __restrict__ wp) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= cl * co * 64) return;
-  const int t = idx & 63, o = (idx >> 6) % co, ci = idx / (64 * co);
-  const int td = t >> 4, th = (t >> 2) & 3, tw = t & 3;
-  const float* wdp = wd + (long long)ci * cu * 8;
+// K4 and its packing for conv_march2_kernel's d2s mode.  Workgroup = (output channel co, four input channels ci: one per wave);
+// W_c[co][Ce:][27] and the four W_d[ci] slices are staged in LDS by coalesced loads (a first version that read W_d from global
+// memory inside the u loop ran at one L2 round trip per iteration: 440 - 860 us); lane = tap t.  The workgroups with
+// blockIdx.y == 0 also produce T[co][k], the bias vector the consumer adds and the 27 border-class corrections of their channel.
+__global__ __launch_bounds__(256) void upcat_compose_kernel(const float* __restrict__ wd, const float* __restrict__ wc, const float* __restrict__ bd,
+                                                            const float* __restrict__ bc, int cl, int cu, int ce, int co,
+                                                            float* __restrict__ k4, bf16_t* __restrict__ wp, float* __restrict__ biasp,
+                                                            float* __restrict__ delta) {
+  extern __shared__ float sm[];                        // wcs[cu][27], wds[4][cu][8], tk[27]
+  float* wcs = sm;
+  float* wds = sm + cu * 27;
+  float* tk = wds + 4 * cu * 8;
+  const int o = blockIdx.x, ci0 = blockIdx.y * 4, tid = threadIdx.x, t = tid & 63, wave = tid >> 6;
   const float* wcp = wc + ((long long)o * (ce + cu) + ce) * 27;
-  float s = 0.f;
-  // (a, k) per axis with a - k + 2 = t: k = a + 2 - t in [0, 2]
-  for (int u = 0; u < cu; ++u) {
-    float su = 0.f;
+  for (int i = tid; i < cu * 27; i += 256) wcs[i] = wcp[i];
+  for (int i = tid; i < 4 * cu * 8; i += 256) wds[i] = (ci0 + i / (cu * 8)) < cl ? wd[(long long)ci0 * cu * 8 + i] : 0.f;
+  __syncthreads();
+  const int ci = ci0 + wave;
+  if (ci < cl) {
+    const int td = t >> 4, th = (t >> 2) & 3, tw = t & 3;
+    // (a, k) per axis with a - k + 2 = t: k = a + 2 - t in [0, 2]
+    int koff[8]; float kok[8];
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
       const int kd = (a >> 2) + 2 - td, kh = ((a >> 1) & 1) + 2 - th, kw = (a & 1) + 2 - tw;
-      if (kd >= 0 && kd <= 2 && kh >= 0 && kh <= 2 && kw >= 0 && kw <= 2) su += wdp[u * 8 + a] * wcp[u * 27 + kd * 9 + kh * 3 + kw];
+      const bool ok = kd >= 0 && kd <= 2 && kh >= 0 && kh <= 2 && kw >= 0 && kw <= 2;
+      kok[a] = ok ? 1.f : 0.f;
+      koff[a] = ok ? kd * 9 + kh * 3 + kw : 0;
     }
-    s += su;
-  }
-  k4[idx] = s;
-  if (wp) {
-    // d2s packing: output class b (voxel 2 j + b) and input tap e (cell j - (1 - b) + e) <-> t = 3 - b - 2 e per axis
-    const int bd = (3 - td) & 1, ed = (3 - td) >> 1, bh = (3 - th) & 1, eh = (3 - th) >> 1, bw = (3 - tw) & 1, ew = (3 - tw) >> 1;
-    const int blk = bd * 4 + bh * 2 + bw, e = ed * 4 + eh * 2 + ew, coutp = 8 * co;
-    wp[(((long long)(ci >> 4) * 8 + e) * coutp + blk * co + o) * 16 + (ci & 15)].v = f32_to_bf16_bits(s);
-  }
-}
-
-// T[co][k], the bias vector the consumer adds and the 27 border-class corrections: one workgroup
-__global__ __launch_bounds__(256) void upcat_bias_kernel(const float* __restrict__ wc, const float* __restrict__ bd, const float* __restrict__ bc,
-                                                         int cu, int ce, int co, float* __restrict__ biasp, float* __restrict__ delta) {
-  extern __shared__ float tk[];                        // [co][27]
-  for (int i = threadIdx.x; i < co * 27; i += 256) {
-    const int o = i / 27, k = i - o * 27;
-    const float* wcp = wc + ((long long)o * (ce + cu) + ce) * 27 + k;
+    const float* wv = wds + wave * cu * 8;
     float s = 0.f;
-    for (int u = 0; u < cu; ++u) s += wcp[u * 27] * bd[u];
-    tk[i] = s;
+    for (int u = 0; u < cu; ++u) {
+      float su = 0.f;
+#pragma unroll
+      for (int a = 0; a < 8; ++a) su += kok[a] * wv[u * 8 + a] * wcs[u * 27 + koff[a]];
+      s += su;
+    }
+    k4[((long long)ci * co + o) * 64 + t] = s;
+    if (wp) {
+      // d2s packing: output class b (voxel 2 j + b) and input tap e (cell j - (1 - b) + e) <-> t = 3 - b - 2 e per axis
+      const int bd_ = (3 - td) & 1, ed = (3 - td) >> 1, bh = (3 - th) & 1, eh = (3 - th) >> 1, bw = (3 - tw) & 1, ew = (3 - tw) >> 1;
+      const int blk = bd_ * 4 + bh * 2 + bw, e = ed * 4 + eh * 2 + ew, coutp = 8 * co;
+      wp[(((long long)(ci >> 4) * 8 + e) * coutp + blk * co + o) * 16 + (ci & 15)].v = f32_to_bf16_bits(s);
+    }
+  }
+  if (biasp == nullptr || blockIdx.y != 0) return;
+  if (tid < 27) {
+    float sv = 0.f;
+    for (int u = 0; u < cu; ++u) sv += wcs[u * 27 + tid] * bd[u];
+    tk[tid] = sv;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 28 * co; i += 256) {
-    const int cls = i / co, o = i - cls * co;
-    if (cls == 27) {
-      float s = bc ? bc[o] : 0.f;
-      for (int k = 0; k < 27; ++k) s += tk[o * 27 + k];
-      biasp[o] = s;
+  if (tid < 28) {
+    if (tid == 27) {
+      float sv = bc ? bc[o] : 0.f;
+      for (int k = 0; k < 27; ++k) sv += tk[k];
+      biasp[o] = sv;
     } else {
       // class (cd, ch, cw) in {0 first voxel, 1 interior, 2 last voxel}: the first voxel lacks tap k = 0, the last one k = 2
-      const int cd = cls / 9, ch = (cls / 3) % 3, cw = cls % 3;
-      float s = 0.f;
+      const int cd = tid / 9, ch = (tid / 3) % 3, cw = tid % 3;
+      float sv = 0.f;
       for (int k = 0; k < 27; ++k) {
         const int kd = k / 9, kh = (k / 3) % 3, kw = k % 3;
         const bool out = (cd == 0 && kd == 0) || (cd == 2 && kd == 2) || (ch == 0 && kh == 0) || (ch == 2 && kh == 2) ||
                          (cw == 0 && kw == 0) || (cw == 2 && kw == 2);
-        if (out) s -= tk[o * 27 + k];
+        if (out) sv -= tk[k];
       }
-      delta[cls * co + o] = s;
+      delta[tid * co + o] = sv;
     }
   }
 }
 
-// chain rule from dK4 (and the border sums of dz) to dW_d, dW_c[:, Ce:], db_d
-__global__ __launch_bounds__(256) void upcat_chain_kernel(const float* __restrict__ dk4, const float* __restrict__ wd, const float* __restrict__ wc,
-                                                          const float* __restrict__ bd, const float* __restrict__ esum, int cl, int cu, int ce, int co,
-                                                          float* __restrict__ dwd, float* __restrict__ dwc, float* __restrict__ dbd, int accumulate) {
-  extern __shared__ float gk[];                        // G_k[co] = sum of dz over the voxels o with o + k - 1 inside: [27][co]
-  for (int i = threadIdx.x; i < 27 * co; i += 256) {
-    const int k = i / co, o = i - k * co;
-    const int kk[3] = {k / 9, (k / 3) % 3, k % 3};
-    // chi_k per axis: k = 0 -> all - first, k = 1 -> all, k = 2 -> all - last; region index s: 0 all, 1 first, 2 last
-    float s = 0.f;
-    for (int sub = 0; sub < 8; ++sub) {
-      int sd = 0, sh = 0, sw = 0, sign = 1;
-      bool ok = true;
-      const int pick[3] = {(sub >> 2) & 1, (sub >> 1) & 1, sub & 1};
-      int* ss[3] = {&sd, &sh, &sw};
-      for (int ax = 0; ax < 3; ++ax) {
-        if (pick[ax]) {
-          if (kk[ax] == 1) { ok = false; break; }
-          *ss[ax] = kk[ax] == 0 ? 1 : 2;
-          sign = -sign;
-        }
+// chain rule from dK4 (and the border sums of dz) to dW_d, dW_c[:, Ce:], db_d.
+// G_k[co] = sum of dz over the voxels o with o + k - 1 inside, from the border-region sums (e[0][0][0], the volume sum, is zero
+// behind a normalisation -- rounding noise in any evaluation -- and is taken as zero)
+__device__ __forceinline__ float upcat_gk(const float* __restrict__ esum, int co, int k, int o) {
+  const int kk[3] = {k / 9, (k / 3) % 3, k % 3};
+  float s = 0.f;
+  for (int sub = 1; sub < 8; ++sub) {
+    int sr[3] = {0, 0, 0}, sign = 1;
+    bool ok = true;
+    for (int ax = 0; ax < 3; ++ax)
+      if ((sub >> (2 - ax)) & 1) {
+        if (kk[ax] == 1) { ok = false; break; }          // chi_k per axis: k = 0 -> all - first, k = 1 -> all, k = 2 -> all - last
+        sr[ax] = kk[ax] == 0 ? 1 : 2;
+        sign = -sign;
       }
-      if (!ok || (sd == 0 && sh == 0 && sw == 0)) continue;     // E[all][all][all] = sum of dz over the volume: exactly zero behind a
-      s += sign * esum[((sd * 3 + sh) * 3 + sw) * co + o];      // normalisation (rounding noise in any evaluation): taken as zero
-    }
-    gk[i] = s;
+    if (ok) s += sign * esum[((sr[0] * 3 + sr[1]) * 3 + sr[2]) * co + o];
   }
+  return s;
+}
+
+// dW_d[ci][u][a] = sum_{o, k} dK4[ci][o][t(a, k)] W_c[o][Ce + u][k].  One WAVE per (ci, u) -- cl * cu small workgroups fill the chip and
+// hide each other's load latency (a 128-workgroup version with LDS staging ran at one memory round trip per 4 o: 64 - 120 us):
+// lane = (a, one of 8 o-slices); the 27 W_c values of an o are wave-uniform per slice, the dK4 row of (ci, o) is one 256-byte line.
+__global__ __launch_bounds__(64) void upcat_chain_wd_kernel(const float* __restrict__ dk4, const float* __restrict__ wc, int cu, int ce, int co,
+                                                            float* __restrict__ dwd, int accumulate) {
+  const int ci = blockIdx.x, u = blockIdx.y, lane = threadIdx.x, a = lane & 7, os = lane >> 3;
+  int tt[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) tt[k] = t_of(a, k);
+  float acc = 0.f;
+  for (int o = os; o < co; o += 8) {
+    const float* d = dk4 + ((long long)ci * co + o) * 64;
+    const float* w = wc + ((long long)o * (ce + cu) + ce + u) * 27;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) s += d[tt[k]] * w[k];
+    acc += s;
+  }
+  // the 8 o-slices of an output, in a fixed order
+  acc += __shfl_xor(acc, 8, 64);
+  acc += __shfl_xor(acc, 16, 64);
+  acc += __shfl_xor(acc, 32, 64);
+  if (os == 0) {
+    float* dst = dwd + ((long long)ci * cu + u) * 8 + a;
+    if (accumulate) *dst += acc; else *dst = acc;
+  }
+}
+
+// dW_c[o][Ce + u][k] = sum_{ci, a} dK4[ci][o][t(a, k)] W_d[ci][u][a] + b_d[u] G_k[o].  Workgroup = (o, 8 channels u): thread = (u, k) (216 of
+// 256); dK4[ci chunk][o][64] and W_d[ci chunk][u tile][8] are staged 16 ci at a time.  The workgroups with blockIdx.x == co compute
+// db_d[u] = sum_{o, k} W_c[o][Ce + u][k] G_k[o] for their 8 channels.
+constexpr int kChainCB = 16;
+__global__ __launch_bounds__(256) void upcat_chain_wc_kernel(const float* __restrict__ dk4, const float* __restrict__ wd, const float* __restrict__ wc,
+                                                             const float* __restrict__ bd, const float* __restrict__ esum, int cl, int cu, int ce,
+                                                             int co, float* __restrict__ dwc, float* __restrict__ dbd, int accumulate) {
+  extern __shared__ float sm[];                        // gk[27][co], dk[kChainCB][64], wds[kChainCB][8][8]
+  float* gk = sm;
+  float* dk = sm + 27 * co;
+  float* wds = dk + kChainCB * 64;
+  const int tid = threadIdx.x, u0 = blockIdx.y * 8;
+  for (int i = tid; i < 27 * co; i += 256) gk[i] = upcat_gk(esum, co, i / co, i % co);
   __syncthreads();
-  const int n_wd = cl * cu * 8, n_wc = co * cu * 27;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx < n_wd) {
-    const int a = idx & 7, u = (idx >> 3) % cu, ci = idx / (8 * cu);
-    float s = 0.f;
-    for (int o = 0; o < co; ++o) {
-      const float* dk = dk4 + ((long long)ci * co + o) * 64;
-      const float* wcp = wc + ((long long)o * (ce + cu) + ce + u) * 27;
+  if ((int)blockIdx.x == co) {
+    if (dbd && tid < 8 && u0 + tid < cu) {
+      float s = 0.f;
+      for (int o = 0; o < co; ++o) {
+        const float* wcp = wc + ((long long)o * (ce + cu) + ce + u0 + tid) * 27;
+        for (int k = 0; k < 27; ++k) s += wcp[k] * gk[k * co + o];
+      }
+      if (accumulate) dbd[u0 + tid] += s; else dbd[u0 + tid] = s;
+    }
+    return;
+  }
+  const int o = blockIdx.x, k = tid % 27, ul = tid / 27;     // ul < 8 for tid < 216
+  int tt[8];
 #pragma unroll
-      for (int k = 0; k < 27; ++k) s += dk[t_of(a, k)] * wcp[k];
+  for (int a = 0; a < 8; ++a) tt[a] = t_of(a, k);
+  float acc = 0.f;
+  for (int c0 = 0; c0 < cl; c0 += kChainCB) {
+    __syncthreads();
+    for (int i = tid; i < kChainCB * 64; i += 256) dk[i] = c0 + (i >> 6) < cl ? dk4[((long long)(c0 + (i >> 6)) * co + o) * 64 + (i & 63)] : 0.f;
+    for (int i = tid; i < kChainCB * 64; i += 256) {
+      const int cb = i >> 6, r = i & 63;               // r = u local * 8 + a
+      wds[i] = (c0 + cb < cl && u0 + (r >> 3) < cu) ? wd[((long long)(c0 + cb) * cu + u0) * 8 + r] : 0.f;
     }
-    if (accumulate) dwd[idx] += s; else dwd[idx] = s;
-  } else if (idx < n_wd + n_wc) {
-    const int j = idx - n_wd, k = j % 27, u = (j / 27) % cu, o = j / (27 * cu);
-    float s = bd ? bd[u] * gk[k * co + o] : 0.f;
-    for (int ci = 0; ci < cl; ++ci) {
-      const float* dk = dk4 + ((long long)ci * co + o) * 64;
-      const float* wdp = wd + ((long long)ci * cu + u) * 8;
+    __syncthreads();
+    if (tid < 216) {
 #pragma unroll
-      for (int a = 0; a < 8; ++a) s += dk[t_of(a, k)] * wdp[a];
+      for (int cb = 0; cb < kChainCB; ++cb) {
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) s += dk[cb * 64 + tt[a]] * wds[cb * 64 + ul * 8 + a];
+        acc += s;
+      }
     }
-    float* dst = dwc + ((long long)o * (ce + cu) + ce + u) * 27 + k;
-    if (accumulate) *dst += s; else *dst = s;
-  } else if (idx < n_wd + n_wc + cu && dbd) {
-    const int u = idx - n_wd - n_wc;
-    float s = 0.f;
-    for (int o = 0; o < co; ++o) {
-      const float* wcp = wc + ((long long)o * (ce + cu) + ce + u) * 27;
-      for (int k = 0; k < 27; ++k) s += wcp[k] * gk[k * co + o];
-    }
-    if (accumulate) dbd[u] += s; else dbd[u] = s;
+  }
+  if (tid < 216 && u0 + ul < cu) {
+    const float v = acc + (bd ? bd[u0 + ul] * gk[k * co + o] : 0.f);
+    float* dst = dwc + ((long long)o * (ce + cu) + ce + u0 + ul) * 27 + k;
+    if (accumulate) *dst += v; else *dst = v;
   }
 }
 
 // ---- sums of a gradient over the 26 border regions of the volume (region = per axis: all voxels / the first one / the last one;
 //      at least one axis restricted).  Stage 1: one workgroup per (n, d) plane -> q[plane][sh][sw][c]; boundary planes sum all
 //      their voxels, interior planes only their border rows / columns.  Stage 2: planes -> e[sd][sh][sw][c].  Fixed orders.
+constexpr int kBorderSplit = 16;                      // workgroups per plane (a boundary plane is 1 MB at 128^2 x 32 channels)
 template <typename T>
 __global__ __launch_bounds__(256) void border_plane_kernel(const T* __restrict__ g, int ld, int d_ext, int h_ext, int w_ext, int c, float* __restrict__ q) {
   constexpr int EPV = Elem<T>::kPer16B;
@@ -172,7 +224,11 @@ __global__ __launch_bounds__(256) void border_plane_kernel(const T* __restrict__
   const T* base = g + (long long)plane * h_ext * w_ext * ld + piece * EPV;
   // candidate voxels: boundary plane -> all; interior plane -> rows 0 / H - 1 in full, columns 0 / W - 1 of the other rows
   const int nfull = bplane ? h_ext * w_ext : 2 * w_ext + 2 * (h_ext - 2);
-  for (int i = vlane; i < nfull; i += vstep) {
+  // a boundary plane is split over the kBorderSplit workgroups of its row; an interior plane's few border voxels are one workgroup's
+  const int nsplit = bplane ? kBorderSplit : 1;
+  if ((int)blockIdx.y >= nsplit) return;               // (border_final_kernel does not read these rows)
+  const int per = (nfull + nsplit - 1) / nsplit, i_end = min(nfull, ((int)blockIdx.y + 1) * per);
+  for (int i = blockIdx.y * per + vlane; i < i_end; i += vstep) {
     int hh, ww;
     if (bplane) { hh = i / w_ext; ww = i - hh * w_ext; }
     else if (i < 2 * w_ext) { hh = i < w_ext ? 0 : h_ext - 1; ww = i < w_ext ? i : i - w_ext; }
@@ -203,21 +259,41 @@ __global__ __launch_bounds__(256) void border_plane_kernel(const T* __restrict__
   __syncthreads();
   for (int i = tid; i < 9 * c; i += 256) {
     const int k = i / c, ch = i - k * c;
-    q[((long long)plane * 9 + k) * c + ch] = (red[0][k][ch] + red[1][k][ch]) + (red[2][k][ch] + red[3][k][ch]);
+    q[(((long long)plane * kBorderSplit + blockIdx.y) * 9 + k) * c + ch] = (red[0][k][ch] + red[1][k][ch]) + (red[2][k][ch] + red[3][k][ch]);
   }
 }
 
+// e[sd][sh][sw][ch]: one workgroup per (sd, sh, sw); its threads = (channel, plane lane) sum the planes' partial rows, then the
+// plane lanes are added through LDS in lane order
 __global__ __launch_bounds__(256) void border_final_kernel(const float* __restrict__ q, int nplanes, int d_ext, int c, float* __restrict__ e) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= 27 * c) return;
-  const int ch = i % c, k9 = (i / c) % 9, sd = i / (9 * c);
+  __shared__ float red[256];
+  const int r = blockIdx.x, sd = r / 9, k9 = r % 9, tid = threadIdx.x;
+  const int ch = tid % c, pl = tid / c, npl = 256 / c;                  // (c divides 64)
   float s = 0.f;
-  if (!(sd == 0 && k9 == 0))
-    for (int p = 0; p < nplanes; ++p) {
-      const int d = p % d_ext;
-      if (sd == 0 || (sd == 1 && d == 0) || (sd == 2 && d == d_ext - 1)) s += q[((long long)p * 9 + k9) * c + ch];
+  if (r != 0) {
+    // (only the first workgroup row of an interior plane holds sums; eight loads in flight per thread, added in a fixed order)
+    const int total = nplanes * kBorderSplit;
+    float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int p0 = pl; p0 < total; p0 += 8 * npl) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int p = p0 + j * npl;
+        if (p < total) {
+          const int d = (p / kBorderSplit) % d_ext, y = p % kBorderSplit;
+          const bool bplane = d == 0 || d == d_ext - 1;
+          if ((bplane || y == 0) && (sd == 0 || (sd == 1 && d == 0) || (sd == 2 && d == d_ext - 1))) part[j] += q[((long long)p * 9 + k9) * c + ch];
+        }
+      }
     }
-  e[i] = s;
+    s = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+  }
+  red[tid] = s;
+  __syncthreads();
+  if (tid < c) {
+    float t = 0.f;
+    for (int j = 0; j < npl; ++j) t += red[j * c + tid];
+    e[r * c + tid] = t;
+  }
 }
 
 }  // namespace
@@ -228,31 +304,29 @@ int mi355_upcat_compose(const float* wd, const float* wc, const float* bd, const
                         int32_t co, float* k4, void* wp_d2s, float* biasp, float* delta, void* stream) {
   MI355_REQUIRE(wd && wc && k4 && cl > 0 && cu > 0 && ce >= 0 && co > 0, "upcat_compose: bad argument");
   MI355_REQUIRE(!wp_d2s || (cl % 16 == 0 && co % 32 == 0), "upcat_compose: the d2s packing needs cl %% 16 == 0 and co %% 32 == 0");
-  MI355_REQUIRE(co * 27 * 4 <= 48 * 1024, "upcat_compose: too many output channels");
-  hipStream_t st = (hipStream_t)stream;
-  const long long total = (long long)cl * co * 64;
-  upcat_compose_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(wd, wc, cl, cu, ce, co, k4, (bf16_t*)wp_d2s);
-  int rc = mi355_check_launch("upcat_compose");
-  if (rc) return rc;
-  if (biasp && delta) {
-    MI355_REQUIRE(bd, "upcat_compose: the bias tables need b_d");
-    upcat_bias_kernel<<<dim3(1), dim3(256), co * 27 * sizeof(float), st>>>(wc, bd, bc, cu, ce, co, biasp, delta);
-    rc = mi355_check_launch("upcat_bias");
-  }
-  return rc;
+  const size_t lds = (size_t)(cu * 27 + 4 * cu * 8 + 27) * sizeof(float);
+  MI355_REQUIRE(lds <= 60 * 1024, "upcat_compose: too many intermediate channels");
+  MI355_REQUIRE((biasp == nullptr) == (delta == nullptr) && (!biasp || bd), "upcat_compose: the bias tables come together and need b_d");
+  upcat_compose_kernel<<<dim3((unsigned)co, (unsigned)((cl + 3) / 4)), dim3(256), lds, (hipStream_t)stream>>>(
+      wd, wc, bd, bc, cl, cu, ce, co, k4, (bf16_t*)wp_d2s, biasp, delta);
+  return mi355_check_launch("upcat_compose");
 }
 
 int mi355_upcat_chain(const float* dk4, const float* wd, const float* wc, const float* bd, const float* esum, int32_t cl, int32_t cu,
                       int32_t ce, int32_t co, float* dwd, float* dwc, float* dbd, int32_t accumulate, void* stream) {
   MI355_REQUIRE(dk4 && wd && wc && esum && dwd && dwc && cl > 0 && cu > 0 && ce >= 0 && co > 0, "upcat_chain: bad argument");
-  MI355_REQUIRE(co * 27 * 4 <= 48 * 1024, "upcat_chain: too many output channels");
-  const long long total = (long long)cl * cu * 8 + (long long)co * cu * 27 + cu;
-  upcat_chain_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), co * 27 * sizeof(float), (hipStream_t)stream>>>(
-      dk4, wd, wc, bd, esum, cl, cu, ce, co, dwd, dwc, dbd, accumulate);
-  return mi355_check_launch("upcat_chain");
+  const size_t lds_c = (size_t)(27 * co + 2 * kChainCB * 64) * sizeof(float);
+  MI355_REQUIRE(lds_c <= 60 * 1024, "upcat_chain: too many output channels");
+  hipStream_t st = (hipStream_t)stream;
+  upcat_chain_wd_kernel<<<dim3((unsigned)cl, (unsigned)cu), dim3(64), 0, st>>>(dk4, wc, cu, ce, co, dwd, accumulate);
+  int rc = mi355_check_launch("upcat_chain_wd");
+  if (rc) return rc;
+  upcat_chain_wc_kernel<<<dim3((unsigned)(co + 1), (unsigned)((cu + 7) / 8)), dim3(256), lds_c, st>>>(
+      dk4, wd, wc, bd, esum, cl, cu, ce, co, dwc, dbd, accumulate);
+  return mi355_check_launch("upcat_chain_wc");
 }
 
-int64_t mi355_border_sums_workspace(int32_t n, int32_t d, int32_t c) { return (int64_t)n * d * 9 * c * 4; }
+int64_t mi355_border_sums_workspace(int32_t n, int32_t d, int32_t c) { return (int64_t)n * d * kBorderSplit * 9 * c * 4; }
 
 int mi355_border_sums(const void* g, int32_t ld, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c, int32_t dtype, float* workspace,
                       float* e, void* stream) {
@@ -261,11 +335,12 @@ int mi355_border_sums(const void* g, int32_t ld, int32_t n, int32_t d, int32_t h
   const int epv = dtype == MI355_DT_F32 ? 4 : 8;
   MI355_REQUIRE(c > 0 && c <= 64 && c % epv == 0 && ld % epv == 0 && 64 % (c / epv) == 0, "border_sums: channels must be 8, 16, 32 or 64 (f32: 4 .. 64)");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MI355_DT_F32) border_plane_kernel<float><<<dim3((unsigned)(n * d)), dim3(256), 0, st>>>((const float*)g, ld, d, h, w, c, workspace);
-  else border_plane_kernel<bf16_t><<<dim3((unsigned)(n * d)), dim3(256), 0, st>>>((const bf16_t*)g, ld, d, h, w, c, workspace);
+  const dim3 grid((unsigned)(n * d), (unsigned)kBorderSplit);
+  if (dtype == MI355_DT_F32) border_plane_kernel<float><<<grid, dim3(256), 0, st>>>((const float*)g, ld, d, h, w, c, workspace);
+  else border_plane_kernel<bf16_t><<<grid, dim3(256), 0, st>>>((const bf16_t*)g, ld, d, h, w, c, workspace);
   int rc = mi355_check_launch("border_sums");
   if (rc) return rc;
-  border_final_kernel<<<dim3((unsigned)((27 * c + 255) / 256)), dim3(256), 0, st>>>(workspace, n * d, d, c, e);
+  border_final_kernel<<<dim3(27), dim3(256), 0, st>>>(workspace, n * d, d, c, e);
   return mi355_check_launch("border_sums_final");
 }
 

@@ -375,7 +375,7 @@ class Convolution(_Mi355Module):
             if feeds is not None and feeds.fp8 and ops.conv_fp8_layer_ok(n, d, h, w, cp, feeds.out_channels):
                 emit8 = feeds.spec.fp8_slot("x", z.device)
             cin = x0.shape[4] + (x1.shape[4] if x1 is not None else 0)
-            if (self.conv.fp8 and torch.is_grad_enabled() and (x0.requires_grad or (x1 is not None and x1.requires_grad))
+            if (self.conv.fp8 and up_from is None and torch.is_grad_enabled() and (x0.requires_grad or (x1 is not None and x1.requires_grad))
                     and ops.conv_fp8_layer_ok(n, d, h, w, cp, cin)):
                 emit8_bwd = self.conv.spec.fp8_slot("g", z.device)
         return Fn.NormActFn.apply(z, part if not small else None, self.adn.N.weight, self.adn.N.bias, shift, self.cfg,
@@ -426,7 +426,7 @@ class UpCat(_Mi355Module):
         co, cl = conv.out_channels, deconv.in_channels
         return (self.fuse_up_branch and self.compute_dtype == torch.bfloat16 and x.dtype == torch.bfloat16
                 and tuple(x_e.shape[1:4]) == tuple(2 * e for e in x.shape[1:4])
-                and co in (32, 64) and cl % 32 == 0 and x.shape[4] == cl and x_e.shape[4] % 16 == 0
+                and co == 32 and cl % 32 == 0 and x.shape[4] == cl and x_e.shape[4] % 16 == 0    # (upcat_1; 64 output channels measured slower)
                 and x_e.shape[4] + deconv.out_channels == conv.in_channels and deconv.bias is not None
                 and x.shape[3] >= 32 and not ops.norm_is_small(x_e.shape[0], *x_e.shape[1:4], co))
 
