@@ -230,7 +230,8 @@ typedef struct mi355_wgrad_desc {
 int64_t mi355_conv_wgrad_workspace(const mi355_wgrad_desc* d);
 int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream);
 /* which kernel family mi355_conv_wgrad takes for this descriptor (tests, profiles): 2 = marching bf16 kernel
- * (3x3x3, W >= 32), 3 = streaming bf16 kernel of the full-resolution 1x1x1 layers, 1 = tile-form bf16 MFMA kernel,
+ * (3x3x3, W >= 32), 3 = streaming bf16 kernel of the full-resolution 1x1x1 layers, 4 = marching bf16 kernel of the dense
+ * 2x2x2 layers (PatchGAN on space-to-depth operands, UpCat's composite kernel; W >= 32), 1 = tile-form bf16 MFMA kernel,
  * 0 = exact-f32 kernel; -1 = invalid descriptor */
 int mi355_conv_wgrad_plan_kind(const mi355_wgrad_desc* d);
 

@@ -245,3 +245,68 @@ def test_gradient_buckets_exchange_only_when_asked_to():
             sink_grad(ps[0])
     finally:
         dist.destroy_process_group()
+
+
+def _worker_flat_buffers(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    from types import SimpleNamespace
+    from oracle import unet_ref as R
+    from unet_bssfp_amd import ddp
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(5)
+        model = SimpleNamespace(gen=R.RefGenerator("bssfp", dropout=0.0).train(), discr=R.RefDiscriminator("bssfp").train())
+        n_before = {k: v.clone() for k, v in model.discr.state_dict().items()}
+        flats = ddp.flatten_buffers(model)
+        assert len(flats) == 2                                # f32 running statistics, int64 batch counters
+        assert ddp.flatten_buffers(model) is flats             # idempotent
+        # the state dict is unchanged (keys, values, the PatchGAN's double registration d1.* / blocks.*) and the buffers are views
+        after = model.discr.state_dict()
+        assert list(after) == list(n_before) and all(torch.equal(after[k], n_before[k]) for k in after)
+        rm = model.discr.d2.bn.running_mean
+        f32 = [f for (dt, _), f in flats.items() if dt == torch.float32][0]
+        assert rm.data_ptr() >= f32.data_ptr() and rm.data_ptr() < f32.data_ptr() + f32.numel() * 4
+        # ranks drift apart (per-rank batch statistics), a forward pass writes THROUGH the views, one broadcast per dtype re-aligns
+        g = torch.Generator().manual_seed(50 + rank)
+        x, y = torch.rand(2, 24, 32, 32, 32, generator=g), torch.rand(2, 6, 32, 32, 32, generator=g)
+        with torch.no_grad():
+            model.discr(x, model.gen(x))
+            model.discr(x, y)
+        assert int(model.discr.d2.bn.num_batches_tracked) == 2 and float(rm.abs().sum()) > 0
+        mine = torch.cat([f.double().reshape(-1) for f in flats.values()])
+        calls = []
+        real = dist.broadcast
+        dist.broadcast = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        try:
+            ddp.broadcast_buffers(model, every=1, step=0)
+        finally:
+            dist.broadcast = real
+        assert len(calls) == 2, calls                          # one collective per dtype, no per-tensor traffic
+        got = torch.cat([f.double().reshape(-1) for f in flats.values()])
+        gathered = [torch.zeros_like(got) for _ in range(world)]
+        dist.all_gather(gathered, got)
+        same = all(torch.equal(t, gathered[0]) for t in gathered)
+        moved = rank == 0 or not torch.equal(mine, got)
+        # ... and the modules see the broadcast values (eval-mode forward equal on both ranks)
+        xe = torch.rand(2, 24, 32, 32, 32, generator=torch.Generator().manual_seed(9))
+        model.gen.eval(); model.discr.eval()
+        with torch.no_grad():
+            out = model.discr(xe, torch.zeros(2, 6, 32, 32, 32)).double().reshape(-1)
+        outs = [torch.zeros_like(out) for _ in range(world)]
+        dist.all_gather(outs, out)
+        # (parameters were seeded identically on both ranks, so equal buffers <=> equal eval outputs)
+        q.put((rank, "ok" if (same and moved and torch.equal(outs[0], outs[1])) else f"FAIL same={same} moved={moved}", None))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, f"FAIL: {e!r} {traceback.format_exc()}", None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_buffer_storage_broadcasts_batchnorm_state_in_one_collective_per_dtype():
+    """ddp.flatten_buffers: the BatchNorm buffers of both networks as views of one flat tensor per dtype -- DDP's per-forward
+    buffer broadcast (src/train.py:30) becomes one collective per dtype without gather / scatter copies."""
+    res = _run(_worker_flat_buffers)
+    assert all(r[1] == "ok" for r in res), res

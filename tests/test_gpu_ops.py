@@ -542,8 +542,9 @@ def test_k4s2_conv_as_dense_k2_on_s2d(hip, dtype, n, cin, cout, sp):
     wide = (n, cin, cout, sp) in S2D_PLANS
     if wide and dtype == torch.float32:
         pytest.skip("the wide cases pin the bf16 marching k2 kernel; f32 takes the same halo kernel as the small cases")
-    plans = []
+    plans, kinds = [], []
     _ops().CONV_PROBE = lambda pid, d, real: plans.append(pid)
+    _ops().WGRAD_PROBE = lambda kind, d: kinds.append(kind)
     g = torch.Generator().manual_seed(17)
     layer = _conv_layer((cin,), cout, 4, 2, 1, 4)
     with torch.no_grad():
@@ -567,8 +568,10 @@ def test_k4s2_conv_as_dense_k2_on_s2d(hip, dtype, n, cin, cout, sp):
         z.backward(to_act(gz, dtype))
     finally:
         _ops().CONV_PROBE = None
+        _ops().WGRAD_PROBE = None
     if wide:
         assert plans == S2D_PLANS[(n, cin, cout, sp)], plans
+        assert kinds == [4], kinds                                       # wgrad_march2_kernel (dense 2x2x2, W >= 32)
     dx = _ops().unpack_ncdhw_s2d(s.grad, cin, sp, cp, 0).cpu()
     close(dx, x_cpu.grad, dtype, "dx")
     close_f32_sum(layer.weight.grad.cpu(), w_cpu.grad, "dw")

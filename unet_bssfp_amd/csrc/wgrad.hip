@@ -758,6 +758,182 @@ __global__ __launch_bounds__(256, 2) void wgrad_deconv_kernel(const WgradArgs a,
 }
 
 // ------------------------------------------------------------------------------------------
+// wgrad_march2_kernel: weight gradient of the dense 2x2x2 stride-1 convolutions on wide tensors -- the PatchGAN's strided blocks on
+// space-to-depth operands (src/model.py:72-82) and the composite kernel of UpCat's fused up-branch (upcat.hip) --
+// marching along d like wgrad_march_kernel.  wgrad_bf16_kernel<2, 2, 4, 32> staged a 3 x 5 x 33 halo per 2 x 4 x 32 outputs through
+// registers with two barriers per tile: 0.15 of the MFMA peak on d1, whose operands alone need 1/4 of its time.
+//   * workgroup = (32 x 32 (ci, co) tile pair, 8 (h) x 32 (w) footprint, segment of output planes); x planes (9 x 33 halo voxels) and
+//     g planes arrive by LDS-DMA two planes ahead: ring of 4 x planes (output plane p pairs with x planes p, p + 1; p + 2 and
+//     p + 3 in flight) and 3 g planes, 128 KB; one barrier per plane with a counted wait for the older copy;
+//   * waves = (w-segment of 16 positions) x (kd): four taps (kh, kw) each -- 32 MFMAs per plane and wave; the 8 g fragments of the
+//     segment stay in registers for the plane, an x fragment of halo row y feeds kh = 0 (output row y) and kh = 1 (row y - 1);
+//   * at the end the two w-segments of a tap are added through LDS in a fixed order: ONE slab per workgroup, reduced in slab
+//     order by the kernels above: bit-identical reruns.
+constexpr int kW2FH = 8, kW2FW = 32, kW2HR = kW2FH + 1, kW2HC = kW2FW + 1;
+constexpr int kW2XI = 20, kW2XS = kW2XI * 1024;       // x plane: 297 halo voxels x 64 B = 18.6 KB -> 20 DMA instructions, 5 per wave
+constexpr int kW2GI = 16, kW2GS = kW2GI * 1024;       // g plane: 256 voxels x 64 B
+constexpr int kW2XR = 4, kW2GR = 3;
+constexpr int kW2Lds = kW2XR * kW2XS + kW2GR * kW2GS;  // 128 KB
+constexpr int kW2PerStep = kW2XI / 4 + kW2GI / 4;     // 9 copies per wave and step
+
+__global__ __launch_bounds__(256, 1) void wgrad_march2_kernel(const WgradArgs a, const WMarchArgs m) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const xs = smem;
+  char* const gsm = smem + kW2XR * kW2XS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int seg = wave & 1, kd = wave >> 1;
+  const int tpairs = m.ci_tiles * m.co_tiles;
+  const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+  const int slab = (kq / tpairs) * 8 + xcd, pair = kq % tpairs;       // (the tile pairs of a slab are neighbours on one XCD: wgrad_march_kernel)
+  if (slab >= m.nslabs) return;
+  const int ci_base = (pair % m.ci_tiles) * 32, co_base = (pair / m.ci_tiles) * 32;
+  const int cx_lim = a.c0 - ci_base, cg_lim = a.cg - co_base;
+  const int per_seg = m.tiles_h * m.tiles_w, per_sample = per_seg * m.nseg;
+  int t = slab;
+  const int tn = t / per_sample;
+  t -= tn * per_sample;
+  const int sg = t / per_seg;
+  t -= sg * per_seg;
+  const int th_i = t / m.tiles_w, tw_i = t - th_i * m.tiles_w;
+  const int d0 = sg * m.seg_len, d1 = min(a.do_, d0 + m.seg_len);
+  const int h0 = th_i * kW2FH, w0 = tw_i * kW2FW;
+
+  const int piece = lane & 3;
+  int xoff[kW2XI / 4], goff[kW2GI / 4];
+#pragma unroll
+  for (int i = 0; i < kW2XI / 4; ++i) {
+    const int v = (i * 4 + wave) * 16 + (lane >> 2);
+    const int y = v / kW2HC, col = v - y * kW2HC;
+    const int gh = h0 + y, gw = w0 + col;
+    const bool ok = v < kW2HR * kW2HC && gh < a.hi && gw < a.wi && piece * 8 < cx_lim;
+    xoff[i] = ok ? ((gh * a.wi + gw) * a.ld0 + ci_base + piece * 8) * 2 : (int)0x80000000;
+  }
+#pragma unroll
+  for (int i = 0; i < kW2GI / 4; ++i) {
+    const int v = (i * 4 + wave) * 16 + (lane >> 2);
+    const int sh = v >> 5, sw = v & 31;
+    const int gh = h0 + sh, gw = w0 + sw;
+    const bool ok = gh < a.ho && gw < a.wo && piece * 8 < cg_lim;
+    goff[i] = ok ? ((gh * a.gw + gw) * a.ldg + co_base + piece * 8) * 2 : (int)0x80000000;
+  }
+  const long long nvx = (long long)a.n * a.di * a.hi * a.wi, nvg = (long long)a.n * a.gd * a.gh * a.gw;
+  const dma_rsrc_t rsx = dma_rsrc(a.x0, ((nvx - 1) * a.ld0 + a.c0) * 2), rsg = dma_rsrc(a.g, ((nvg - 1) * a.ldg + a.cg) * 2);
+  const int xplane = a.hi * a.wi * a.ld0 * 2, gplane = a.gh * a.gw * a.ldg * 2;
+  auto load_x = [&](int q) __attribute__((always_inline)) {           // x plane q -> ring slot q % 4 (beyond the tensor: zeros)
+    const bool pin = q < a.di;
+    const int soff = pin ? (tn * a.di + q) * xplane : 0, kill = pin ? 0 : (int)0x80000000;
+    char* dst = xs + ((unsigned)q % kW2XR) * kW2XS + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < kW2XI / 4; ++i) dma_lds_b128(rsx, dst + i * 4096, xoff[i] | kill, soff);
+  };
+  auto load_g = [&](int p) __attribute__((always_inline)) {
+    const bool pin = p < d1;
+    const int soff = pin ? (tn * a.gd + p) * gplane : 0, kill = pin ? 0 : (int)0x80000000;
+    char* dst = gsm + ((unsigned)p % kW2GR) * kW2GS + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < kW2GI / 4; ++i) dma_lds_b128(rsg, dst + i * 4096, goff[i] | kill, soff);
+  };
+  load_x(d0);
+  load_x(d0 + 1);
+  load_x(d0 + 2);
+  load_g(d0);
+  load_g(d0 + 1);
+
+  f32x16 acc[2][2];                                                    // [kh][kw]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[i][k][j] = 0.f;
+  const int gi = lane & 15;
+  const int lane_off = (8 * h + (gi >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (gi & 3)) * 2;     // frag_tr's lane pattern
+  const int seg_lane_off = seg * 16 * 64 + lane_off;
+  dma_wait_all();
+  __syncthreads();
+  for (int p = d0; p < d1; ++p) {
+    // this step's copies: x plane p + 3 (tickets 0 .. 4), g plane p + 2 (tickets 5 .. 8), one behind each halo row's MFMAs
+    const int qx = p + 3, pg = p + 2;
+    const bool pinx = qx < a.di, ping = pg < d1;
+    const int soffx = pinx ? (tn * a.di + qx) * xplane : 0, soffg = ping ? (tn * a.gd + pg) * gplane : 0;
+    const int killx = pinx ? 0 : (int)0x80000000, killg = ping ? 0 : (int)0x80000000;
+    char* const dstx = xs + ((unsigned)qx % kW2XR) * kW2XS + wave * 1024;
+    char* const dstg = gsm + ((unsigned)pg % kW2GR) * kW2GS + wave * 1024;
+    const char* gp = gsm + ((unsigned)p % kW2GR) * kW2GS + seg_lane_off;
+    const char* xp = xs + ((unsigned)(p + kd) % kW2XR) * kW2XS + seg_lane_off;
+    bf16x8 gf[kW2FH];
+#pragma unroll
+    for (int sh = 0; sh < kW2FH; ++sh) gf[sh] = frag_tr(gp + sh * (kW2FW * 64));
+    bf16x8 xf[2][2];
+#pragma unroll
+    for (int kw = 0; kw < 2; ++kw) xf[0][kw] = frag_tr(xp + kw * 64);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * kW2FH + 4, 0);
+#pragma unroll
+    for (int y = 0; y < kW2HR; ++y) {
+      if (y + 1 < kW2HR) {
+#pragma unroll
+        for (int kw = 0; kw < 2; ++kw) xf[(y + 1) & 1][kw] = frag_tr(xp + (y + 1) * (kW2HC * 64) + kw * 64);
+      }
+      int nm = 0;
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        const int row = y - kh;
+        if (row >= 0 && row < kW2FH) {
+#pragma unroll
+          for (int kw = 0; kw < 2; ++kw) acc[kh][kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[y & 1][kw], gf[row], acc[kh][kw], 0, 0, 0);
+          nm += 2;
+        }
+      }
+      // the row's MFMAs with the next row's four transposed reads spread between them
+      const int nrd = y + 1 < kW2HR ? 4 : 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (k < nm) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        const int nr = nm ? (nrd * (k + 1) / nm - nrd * k / nm) : 0;
+        if (k < nm && nr == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        else if (k < nm && nr == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      static_assert(kW2PerStep == kW2HR, "one copy ticket per halo row");
+      if (y < kW2XI / 4) dma_lds_b128(rsx, dstx + y * 4096, xoff[y] | killx, soffx);
+      else dma_lds_b128(rsg, dstg + (y - kW2XI / 4) * 4096, goff[y - kW2XI / 4] | killg, soffg);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kW2PerStep) : "memory");   // x plane p + 2, g plane p + 1 have landed (this wave's share) ...
+    __syncthreads();                                                    // ... everybody's; every wave is done with this plane's slots
+  }
+  dma_wait_all();
+  __syncthreads();
+  // ---- the two w-segments of a tap: segment 1 parks, segment 0 adds (fixed order) and writes the workgroup's slab
+  float* const park = reinterpret_cast<float*>(smem) + lane;           // [kd][kh][kw][j][lane]
+  if (seg == 1) {
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 2; ++kw)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) park[((((kd * 2 + kh) * 2 + kw) * 16) + j) * 64] = acc[kh][kw][j];
+  }
+  __syncthreads();
+  if (seg == 0) {
+    float* sl = a.slab + (long long)slab * 8 * a.cinp * a.coutp;
+    const int co = co_base + r;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 2; ++kw) {
+        const int tap = (kd * 2 + kh) * 2 + kw;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const float v = acc[kh][kw][j] + park[((((kd * 2 + kh) * 2 + kw) * 16) + j) * 64];
+          sl[((long long)tap * a.cinp + ci_base + acc_row(j, h)) * a.coutp + co] = v;
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // wgrad_pw_kernel: weight gradient of the full-resolution 1x1x1 convolutions with <= 32 channels either side (generator
 // head 24 -> 24, src/model.py:21; final_conv 32 -> 6, MONAI BasicUNet at :22-28): D[ci][co] = sum_v x[v][ci] g[v][co] over
 // ~2 M voxels -- 64 + 32..64 bytes per voxel for 2 K FLOP, a pure HBM stream.  wgrad_bf16_kernel<1, ...> staged 256-voxel
@@ -832,7 +1008,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_pw_kernel(const WgradArgs a, con
 
 struct WPlan { int ks, tpw, tap_groups, ci_tiles, co_tiles, splits, cinp32, coutp32; long long rows;
                bool fast, deconv4; int shape, tiles_d, tiles_h, tiles_w, ntiles, nslabs;
-               bool march; int seg_len, nseg; bool pw; };
+               bool march; int seg_len, nseg; bool pw; bool march2; };
 
 const int kWTD[2] = {2, 2}, kWTH[2] = {4, 8}, kWTW[2] = {32, 16};
 
@@ -910,6 +1086,27 @@ int wplan(const mi355_wgrad_desc* d, WPlan* p) {
       p->nslabs = 256;
     }
   }
+  // marching k2 kernel: dense 2x2x2, padding 0, x one larger than the grid, wide rows; 32-bit byte offsets
+  p->march2 = false;
+  if (p->fast && !cls && d->ks == 2 && d->c1 == 0 && d->pad[0] == 0 && d->pad[1] == 0 && d->pad[2] == 0 && d->di == d->do_ + 1 &&
+      d->hi == d->ho + 1 && d->wi == d->wo + 1 && d->wo >= 32 && d->do_ >= 4 && d->xn == 0 &&
+      (long long)d->n * d->di * d->hi * d->wi * std::max(d->ld0, d->ldg) * 2 < (1ll << 31)) {
+    const int th = ceil_div(d->ho, kW2FH), tw = ceil_div(d->wo, kW2FW);
+    const long long base = (long long)d->n * th * tw * p->ci_tiles * p->co_tiles;
+    long long best = -1; int best_ns = 1;
+    for (int ns = 1; ns <= d->do_ / 2; ++ns) {
+      const int L = ceil_div(d->do_, ns);
+      if ((long long)(ns - 1) * L >= d->do_) continue;
+      const long long wgs = base * ns, cost = ((wgs + 255) / 256) * (L + 3);
+      if ((long long)ns * d->n * th * tw * slab_bytes > (256ll << 20)) break;
+      if (best < 0 || cost < best) { best = cost; best_ns = ns; }
+    }
+    p->march2 = true;
+    p->nseg = best_ns;
+    p->seg_len = ceil_div(d->do_, best_ns);
+    p->tiles_h = th; p->tiles_w = tw;
+    p->nslabs = d->n * th * tw * best_ns;
+  }
   // marching kernel: 3x3x3, padding 1, same extents, wide rows; 32-bit byte offsets
   p->march = false;
   if (p->fast && !cls && d->ks == 3 && d->pad[0] == 1 && d->pad[1] == 1 && d->pad[2] == 1 && d->di == d->do_ && d->hi == d->ho &&
@@ -957,7 +1154,7 @@ extern "C" int64_t mi355_conv_wgrad_workspace(const mi355_wgrad_desc* d) {
 extern "C" int mi355_conv_wgrad_plan_kind(const mi355_wgrad_desc* d) {
   WPlan p;
   if (wplan(d, &p)) return -1;
-  return p.march ? 2 : (p.pw ? 3 : (p.fast ? 1 : 0));
+  return p.march ? 2 : (p.pw ? 3 : (p.march2 ? 4 : (p.fast ? 1 : 0)));
 }
 
 extern "C" int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream) {
@@ -989,6 +1186,11 @@ extern "C" int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream) {
     static const int attr = (int)hipFuncSetAttribute((const void*)wgrad_pw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPwLds);
     if (attr) { mi355_set_error("wgrad_pw: cannot raise the dynamic LDS limit to %d bytes (hip error %d)", kPwLds, attr); return MI355_ERR_HIP; }
     wgrad_pw_kernel<<<dim3(256), dim3(256), kPwLds, st>>>(a, nv, (int)((nv + 63) / 64));
+  } else if (p.march2) {
+    const WMarchArgs m{p.seg_len, p.nseg, p.tiles_h, p.tiles_w, p.nslabs, p.ci_tiles, p.co_tiles};
+    static const int attr = (int)hipFuncSetAttribute((const void*)wgrad_march2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kW2Lds);
+    if (attr) { mi355_set_error("wgrad_march2: cannot raise the dynamic LDS limit to %d bytes (hip error %d)", kW2Lds, attr); return MI355_ERR_HIP; }
+    wgrad_march2_kernel<<<dim3(((p.nslabs + 7) / 8) * 8 * p.ci_tiles * p.co_tiles), dim3(256), kW2Lds, st>>>(a, m);
   } else if (p.march) {
     const WMarchArgs m{p.seg_len, p.nseg, p.tiles_h, p.tiles_w, p.nslabs, p.ci_tiles, p.co_tiles};
     static const int attr = (int)hipFuncSetAttribute((const void*)wgrad_march_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWmLds);

@@ -173,12 +173,56 @@ def attach(model, bucket_mb: float = 25.0, group=None, broadcast: bool = True):
     return model
 
 
+def flatten_buffers(model):
+    """Move every buffer of ``model.gen`` / ``model.discr`` (BatchNorm running statistics, batch counters) into ONE flat tensor
+    per dtype and re-register the buffers as views of it: ``broadcast_buffers`` is then one ``dist.broadcast`` per dtype with no
+    gather / scatter copies (it was 4 collectives and ~30 small kernels between two graph replays, every step).  Call it once the
+    model sits on its device and BEFORE a step is captured (the kernels keep writing through the buffers' pointers);
+    ``load_state_dict`` copies in place and keeps the views.  Returns {dtype: flat tensor}."""
+    flats = getattr(model, "_flat_buffers", None)
+    if flats is not None:
+        return flats
+    by_dtype, seen = {}, set()
+    for net in (model.gen, model.discr):
+        for mod in net.modules():
+            for name, b in list(mod._buffers.items()):
+                if b is not None and id(b) not in seen:
+                    seen.add(id(b))
+                    by_dtype.setdefault((b.dtype, b.device), []).append((mod, name, b))
+    flats = {}
+    with torch.no_grad():
+        for (dt, dev), items in by_dtype.items():
+            flat = torch.empty(sum(b.numel() for _, _, b in items), dtype=dt, device=dev)
+            off = 0
+            for mod, name, b in items:
+                view = flat[off: off + b.numel()].view_as(b)
+                view.copy_(b)
+                # (a module registered under several names -- the PatchGAN's d1 / blocks -- is visited once; every alias of the
+                #  buffer OBJECT inside other modules' tables is re-pointed as well)
+                for other in (model.gen, model.discr):
+                    for m2 in other.modules():
+                        for n2, b2 in m2._buffers.items():
+                            if b2 is b:
+                                m2._buffers[n2] = view
+                off += b.numel()
+            flats[(dt, dev)] = flat
+    model._flat_buffers = flats
+    return flats
+
+
 def broadcast_buffers(model, every: int = 1, step: int = 0, group=None):
     """DDP's ``broadcast_buffers=True`` (implied by src/train.py:30): rank 0's BatchNorm running statistics to every rank.
     The statistics are computed per rank (no SyncBatchNorm, as in the reference), so without this the eval-mode outputs
     of the generator head and of the PatchGAN drift apart between ranks.  ``every`` = k broadcasts only every k-th step
-    (the buffers are ~8 KB; k = 1 reproduces DDP's per-forward broadcast at step granularity)."""
+    (the buffers are ~8 KB; k = 1 reproduces DDP's per-forward broadcast at step granularity).  After ``flatten_buffers`` this is
+    one collective per dtype on the flat storage, without copies."""
     if every > 0 and step % every == 0:
+        flats = getattr(model, "_flat_buffers", None)
+        if flats is not None:
+            if dist.is_initialized() and dist.get_world_size(group) > 1:
+                for flat in flats.values():
+                    dist.broadcast(flat, src=0, group=group)
+            return
         broadcast_module_state(model.gen, 0, group, buffers_only=True)
         broadcast_module_state(model.discr, 0, group, buffers_only=True)
 

@@ -470,6 +470,9 @@ class GraphedTrainingStep:
             if not model.enable_grad_sinks(group, distributed=True, force_collectives=force_collectives):
                 raise RuntimeError("GraphedTrainingStep with world size > 1 needs the HIP networks on the GPU")
             model.sinks_gen.auto_launch = model.sinks_discr.auto_launch = False      # launched between the segments
+        if self.broadcast_buffers_every:
+            from . import ddp
+            ddp.flatten_buffers(model)                       # one flat tensor per dtype: the per-step broadcast is one collective each, no copies
         self.launch_log = []                                # (what, position) of the latest step: tests
         for _ in range(max(2, warmup)):                     # eager: allocations, caches, optimiser state
             self._eager_step()
