@@ -205,15 +205,19 @@ __global__ __launch_bounds__(256) void upcat_chain_wc_kernel(const float* __rest
 }
 
 // ---- sums of a gradient over the 26 border regions of the volume (region = per axis: all voxels / the first one / the last one;
-//      at least one axis restricted).  Stage 1: one workgroup per (n, d) plane -> q[plane][sh][sw][c]; boundary planes sum all
-//      their voxels, interior planes only their border rows / columns.  Stage 2: planes -> e[sd][sh][sw][c].  Fixed orders.
-constexpr int kBorderSplit = 16;                      // workgroups per plane (a boundary plane is 1 MB at 128^2 x 32 channels)
+//      at least one axis restricted).  Stage 1, a compact work list per sample: the two boundary planes in kBorderSplit pieces each
+//      (all their voxels), then the D - 2 interior planes (their border rows / columns only: a few hundred voxels) ->
+//      q[item][sh][sw][c].  Stage 2: items -> e[sd][sh][sw][c].  Fixed orders, no atomics.
+constexpr int kBorderSplit = 64;
+__host__ __device__ inline int border_items(int d_ext) { return 2 * kBorderSplit + d_ext - 2; }
+
 template <typename T>
 __global__ __launch_bounds__(256) void border_plane_kernel(const T* __restrict__ g, int ld, int d_ext, int h_ext, int w_ext, int c, float* __restrict__ q) {
   constexpr int EPV = Elem<T>::kPer16B;
-  __shared__ float red[4][9][8 * 8];                   // [wave][combo][piece * EPV + j]  (c <= 64: up to 16 pieces of 4 / 8 of 8)
-  const int plane = blockIdx.x, d = plane % d_ext;
-  const bool bplane = d == 0 || d == d_ext - 1;
+  __shared__ float red[4][9][8 * 8];                   // [wave][combo][piece * EPV + j]  (c <= 64)
+  const int per_n = border_items(d_ext), n = blockIdx.x / per_n, it = blockIdx.x - n * per_n;
+  const bool bplane = it < 2 * kBorderSplit;
+  const int d = bplane ? (it < kBorderSplit ? 0 : d_ext - 1) : it - 2 * kBorderSplit + 1;
   const int pieces = c / EPV, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int piece = tid % pieces, vlane = tid / pieces, vstep = 256 / pieces;
   float acc[9][EPV];
@@ -221,14 +225,12 @@ __global__ __launch_bounds__(256) void border_plane_kernel(const T* __restrict__
   for (int k = 0; k < 9; ++k)
 #pragma unroll
     for (int j = 0; j < EPV; ++j) acc[k][j] = 0.f;
-  const T* base = g + (long long)plane * h_ext * w_ext * ld + piece * EPV;
-  // candidate voxels: boundary plane -> all; interior plane -> rows 0 / H - 1 in full, columns 0 / W - 1 of the other rows
+  const T* base = g + ((long long)n * d_ext + d) * h_ext * w_ext * ld + piece * EPV;
+  // candidate voxels: a piece of a boundary plane; an interior plane's rows 0 / H - 1 in full and columns 0 / W - 1 of the other rows
   const int nfull = bplane ? h_ext * w_ext : 2 * w_ext + 2 * (h_ext - 2);
-  // a boundary plane is split over the kBorderSplit workgroups of its row; an interior plane's few border voxels are one workgroup's
-  const int nsplit = bplane ? kBorderSplit : 1;
-  if ((int)blockIdx.y >= nsplit) return;               // (border_final_kernel does not read these rows)
-  const int per = (nfull + nsplit - 1) / nsplit, i_end = min(nfull, ((int)blockIdx.y + 1) * per);
-  for (int i = blockIdx.y * per + vlane; i < i_end; i += vstep) {
+  const int per = bplane ? (nfull + kBorderSplit - 1) / kBorderSplit : nfull;
+  const int i0 = bplane ? (it % kBorderSplit) * per : 0, i_end = min(nfull, i0 + per);
+  for (int i = i0 + vlane; i < i_end; i += vstep) {
     int hh, ww;
     if (bplane) { hh = i / w_ext; ww = i - hh * w_ext; }
     else if (i < 2 * w_ext) { hh = i < w_ext ? 0 : h_ext - 1; ww = i < w_ext ? i : i - w_ext; }
@@ -259,30 +261,27 @@ __global__ __launch_bounds__(256) void border_plane_kernel(const T* __restrict__
   __syncthreads();
   for (int i = tid; i < 9 * c; i += 256) {
     const int k = i / c, ch = i - k * c;
-    q[(((long long)plane * kBorderSplit + blockIdx.y) * 9 + k) * c + ch] = (red[0][k][ch] + red[1][k][ch]) + (red[2][k][ch] + red[3][k][ch]);
+    q[((long long)blockIdx.x * 9 + k) * c + ch] = (red[0][k][ch] + red[1][k][ch]) + (red[2][k][ch] + red[3][k][ch]);
   }
 }
 
-// e[sd][sh][sw][ch]: one workgroup per (sd, sh, sw); its threads = (channel, plane lane) sum the planes' partial rows, then the
-// plane lanes are added through LDS in lane order
-__global__ __launch_bounds__(256) void border_final_kernel(const float* __restrict__ q, int nplanes, int d_ext, int c, float* __restrict__ e) {
+// e[sd][sh][sw][ch]: one workgroup per (sd, sh, sw); its threads = (channel, item lane) sum their share of the region's items
+// (first plane's pieces / last plane's pieces / everything), eight loads in flight, then the lanes are added through LDS in lane order
+__global__ __launch_bounds__(256) void border_final_kernel(const float* __restrict__ q, int nsamples, int d_ext, int c, float* __restrict__ e) {
   __shared__ float red[256];
   const int r = blockIdx.x, sd = r / 9, k9 = r % 9, tid = threadIdx.x;
   const int ch = tid % c, pl = tid / c, npl = 256 / c;                  // (c divides 64)
+  const int per_n = border_items(d_ext);
+  const int lo = sd == 2 ? kBorderSplit : 0, cnt = sd == 0 ? per_n : kBorderSplit;   // the region's items within a sample
   float s = 0.f;
   if (r != 0) {
-    // (only the first workgroup row of an interior plane holds sums; eight loads in flight per thread, added in a fixed order)
-    const int total = nplanes * kBorderSplit;
+    const int total = nsamples * cnt;
     float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int p0 = pl; p0 < total; p0 += 8 * npl) {
+    for (int i0 = pl; i0 < total; i0 += 8 * npl) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int p = p0 + j * npl;
-        if (p < total) {
-          const int d = (p / kBorderSplit) % d_ext, y = p % kBorderSplit;
-          const bool bplane = d == 0 || d == d_ext - 1;
-          if ((bplane || y == 0) && (sd == 0 || (sd == 1 && d == 0) || (sd == 2 && d == d_ext - 1))) part[j] += q[((long long)p * 9 + k9) * c + ch];
-        }
+        const int i = i0 + j * npl;
+        if (i < total) part[j] += q[(((long long)(i / cnt) * per_n + lo + i % cnt) * 9 + k9) * c + ch];
       }
     }
     s = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
@@ -326,7 +325,7 @@ int mi355_upcat_chain(const float* dk4, const float* wd, const float* wc, const 
   return mi355_check_launch("upcat_chain_wc");
 }
 
-int64_t mi355_border_sums_workspace(int32_t n, int32_t d, int32_t c) { return (int64_t)n * d * kBorderSplit * 9 * c * 4; }
+int64_t mi355_border_sums_workspace(int32_t n, int32_t d, int32_t c) { return (int64_t)n * border_items(d) * 9 * c * 4; }
 
 int mi355_border_sums(const void* g, int32_t ld, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c, int32_t dtype, float* workspace,
                       float* e, void* stream) {
@@ -335,12 +334,12 @@ int mi355_border_sums(const void* g, int32_t ld, int32_t n, int32_t d, int32_t h
   const int epv = dtype == MI355_DT_F32 ? 4 : 8;
   MI355_REQUIRE(c > 0 && c <= 64 && c % epv == 0 && ld % epv == 0 && 64 % (c / epv) == 0, "border_sums: channels must be 8, 16, 32 or 64 (f32: 4 .. 64)");
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)(n * d), (unsigned)kBorderSplit);
+  const dim3 grid((unsigned)(n * border_items(d)));
   if (dtype == MI355_DT_F32) border_plane_kernel<float><<<grid, dim3(256), 0, st>>>((const float*)g, ld, d, h, w, c, workspace);
   else border_plane_kernel<bf16_t><<<grid, dim3(256), 0, st>>>((const bf16_t*)g, ld, d, h, w, c, workspace);
   int rc = mi355_check_launch("border_sums");
   if (rc) return rc;
-  border_final_kernel<<<dim3(27), dim3(256), 0, st>>>(workspace, n * d, d, c, e);
+  border_final_kernel<<<dim3(27), dim3(256), 0, st>>>(workspace, n, d, c, e);
   return mi355_check_launch("border_sums_final");
 }
 
