@@ -194,6 +194,11 @@ int mi355_border_sums(const void* g, int32_t ld, int32_t n, int32_t d, int32_t h
                       float* e, void* stream);
 int mi355_s2d_repack(const void* src, int32_t ld_src, void* dst, int32_t ld_dst, int32_t n, int32_t d, int32_t h, int32_t w,
                      int32_t c, int32_t dtype, void* stream);
+/* Gradient seam PatchGAN -> generator (src/model.py:172, 268): dz[n][v][0..cpad) = g_ncdhw[n][ch][v] (f32 NCDHW gradient of the
+ * generator's output from the loss head; NULL = absent) + the space-to-depth gradient g_s2d of S(output) (cblk channels per block;
+ * NULL = absent), channels >= c zero: the NDHWC gradient the final convolution's backward reads, in one pass. */
+int mi355_seam_grad(const float* g_ncdhw, const void* g_s2d, int32_t ld_s, int32_t cblk, void* dz, int32_t ld_dz, int32_t cpad,
+                    int32_t n, int32_t c, int32_t d, int32_t h, int32_t w, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Weight gradient (autograd of Conv3d / ConvTranspose3d weights).

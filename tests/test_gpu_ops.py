@@ -886,3 +886,36 @@ def test_upcat_fused_up_branch_matches_torch(hip, n, ce, cl, cu, co, low):
     bd_ref = bd.grad - torch.einsum("ock,o->c", wc.detach()[:, ce:].reshape(co, cu, 27), gsum)
     close_f32_sum(deconv.bias.grad.cpu(), bd_ref, "db_d")
     assert float(conv.bias.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("which", ["both", "loss_only", "discr_only"])
+def test_generator_output_seam_equals_unpack_add_pack(hip, which):
+    """Fn.GenOutFn: the generator's NDHWC output -> (NCDHW f32, S(output)); its backward joins the loss head's NCDHW gradient and
+    the PatchGAN's space-to-depth gradient in one pass (mi355_seam_grad).  Against the separate kernels it replaces: unpack,
+    pack_ncdhw_s2d forward; unpack_ncdhw_s2d + add + pack_ncdhw backward -- bit for bit (f32 add, one rounding to bf16)."""
+    from unet_bssfp_amd import functional as Fn
+    ops = _ops()
+    dtype, sp, n = torch.bfloat16, (8, 12, 16), 2
+    g = torch.Generator().manual_seed(41)
+    z = to_act(q(torch.rand(n, 6, *sp, generator=g) - 0.5, dtype), dtype).requires_grad_(True)       # (n, d, h, w, 16)
+    y, s = Fn.GenOutFn.apply(z, 6, 8)
+    assert torch.equal(y, ops.unpack_ncdhw(z.detach(), 6, 0))
+    ref_s = torch.zeros(ops.s2d_shape(n, *sp, 8), dtype=dtype, device=DEV)
+    ops.pack_ncdhw_s2d(y.detach(), ref_s, 8, 0, 8)
+    assert torch.equal(s, ref_s)
+    gy = (torch.rand(n, 6, *sp, generator=g) - 0.5).to(DEV)
+    gs = to_s2d(q(torch.rand(n, 6, *sp, generator=g) - 0.5, dtype), dtype, 8)
+    outs, grads = [], []
+    if which != "discr_only":
+        outs.append(y); grads.append(gy)
+    if which != "loss_only":
+        outs.append(s); grads.append(gs)
+    torch.autograd.backward(outs, grads)
+    total = torch.zeros(n, 6, *sp, device=DEV)
+    if which != "discr_only":
+        total = total + gy
+    if which != "loss_only":
+        total = total + ops.unpack_ncdhw_s2d(gs, 6, sp, 8, 0)
+    ref = ops.new_act(n, *sp, 16, dtype, DEV)
+    ops.pack_ncdhw(total.contiguous(), ref, 0, 16)
+    assert torch.equal(z.grad, ref)

@@ -80,6 +80,7 @@ _SIGNATURES = {
     "mi355_border_sums_workspace": (_i64, [_i32, _i32, _i32]),
     "mi355_border_sums": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "mi355_s2d_repack": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mi355_seam_grad": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mi355_weight_pack": (C.c_int, [C.POINTER(WpackDesc), _vp]),
     "mi355_weight_pack_multi": (C.c_int, [C.POINTER(WpackDesc), _i32, _vp]),
     "mi355_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), _vp]),

@@ -152,6 +152,33 @@ __global__ __launch_bounds__(256) void s2d_repack_kernel(const T* __restrict__ s
   s2d_zero_siblings<T>(dst, q, srow, blk, border, ldd, piece * EPV);
 }
 
+// Gradient seam between the PatchGAN and the generator (src/model.py:172, 268: the generator phase back-propagates through D into
+// G): dz[v][ch] = g_ncdhw[ch][v] (the loss head's gradient of the NCDHW output, or absent) + unS(g_s)[v][ch] (the PatchGAN's
+// gradient of S(y_hat), or absent), as the NDHWC activation gradient the final convolution's backward reads.  One pass instead of
+// unpack (S -> NCDHW f32) + add + pack (NCDHW f32 -> NDHWC).  thread = (voxel, 16-byte piece of the output row)
+template <typename T>
+__global__ __launch_bounds__(256) void seam_grad_kernel(const float* __restrict__ gy, const T* __restrict__ gs, int ld_s, T* __restrict__ dz, int ld_dz,
+                                                        int pieces, int c, long long v, S2D q) {
+  constexpr int EPV = Elem<T>::kPer16B;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long vox = idx / pieces;
+  const int piece = (int)(idx - vox * pieces), n = blockIdx.y;
+  if (vox >= v) return;
+  Vec16<T> o;
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) {
+    const int ch = piece * EPV + j;
+    o.f[j] = (gy && ch < c) ? gy[((long long)n * c + ch) * v + vox] : 0.f;
+  }
+  if (gs && piece * EPV < q.cblk) {
+    Vec16<T> sv;
+    sv.load(gs + s2d_offset(q, (long long)n * v + vox, ld_s) + piece * EPV);
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) o.f[j] += sv.f[j];
+  }
+  o.store(dz + ((long long)n * v + vox) * ld_dz + piece * EPV);
+}
+
 // ------------------------------------------------------------------ weight pack
 struct WpackArgs {
   const float* src; void* dst;
@@ -1213,6 +1240,26 @@ int mi355_s2d_repack(const void* src, int32_t ld_src, void* dst, int32_t ld_dst,
   if (dtype == MI355_DT_F32) s2d_repack_kernel<float><<<grid, dim3(256), 0, (hipStream_t)stream>>>((const float*)src, ld_src, (float*)dst, ld_dst, v, pieces, q);
   else s2d_repack_kernel<bf16_t><<<grid, dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst, v, pieces, q);
   return mi355_check_launch("s2d_repack");
+}
+
+int mi355_seam_grad(const float* g_ncdhw, const void* g_s2d, int32_t ld_s, int32_t cblk, void* dz, int32_t ld_dz, int32_t cpad,
+                    int32_t n, int32_t c, int32_t d, int32_t h, int32_t w, int32_t dtype, void* stream) {
+  MI355_REQUIRE(dz && (g_ncdhw || g_s2d) && n > 0 && c > 0, "seam_grad: bad argument");
+  MI355_REQUIRE(dtype == MI355_DT_F32 || dtype == MI355_DT_BF16, "seam_grad: bad dtype");
+  const int epv = dtype == MI355_DT_F32 ? 4 : 8;
+  MI355_REQUIRE(cpad % epv == 0 && cpad >= c && ld_dz >= cpad && ld_dz % epv == 0, "seam_grad: bad output row");
+  if (g_s2d) {
+    int rc = check_s2d(d, h, w, cblk, ld_s, "seam_grad");
+    if (rc) return rc;
+    MI355_REQUIRE(cblk % epv == 0 && cblk <= cpad && ld_s % epv == 0, "seam_grad: bad space-to-depth block");
+  }
+  const long long v = (long long)d * h * w;
+  const int pieces = cpad / epv;
+  const dim3 grid((unsigned)((v * pieces + 255) / 256), (unsigned)n);
+  const S2D q{d, h, w, g_s2d ? cblk : 0};
+  if (dtype == MI355_DT_F32) seam_grad_kernel<float><<<grid, dim3(256), 0, (hipStream_t)stream>>>(g_ncdhw, (const float*)g_s2d, ld_s, (float*)dz, ld_dz, pieces, c, v, q);
+  else seam_grad_kernel<bf16_t><<<grid, dim3(256), 0, (hipStream_t)stream>>>(g_ncdhw, (const bf16_t*)g_s2d, ld_s, (bf16_t*)dz, ld_dz, pieces, c, v, q);
+  return mi355_check_launch("seam_grad");
 }
 
 int mi355_weight_pack(const mi355_wpack_desc* d, void* stream) {

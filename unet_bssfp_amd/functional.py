@@ -408,6 +408,30 @@ class UnpackFn(Function):
         return out, None
 
 
+class GenOutFn(Function):
+    """The generator's NDHWC output -> (contiguous NCDHW f32 tensor handed to the caller, S(output) for the PatchGAN's first block:
+    Discriminator reads ``y._mi355_s2d`` instead of packing the f32 tensor again).  Backward: ONE pass joins the loss head's NCDHW
+    gradient and the PatchGAN's space-to-depth gradient into the NDHWC gradient of the final convolution (src/model.py:172, 268) --
+    before: unpack S -> NCDHW f32, an add over the f32 tensors, pack NCDHW -> NDHWC."""
+
+    @staticmethod
+    def forward(ctx, act, c, cblk):
+        act = ops.as_act(act)
+        ctx.meta = (tuple(act.shape), act.dtype, c)
+        ctx.set_materialize_grads(False)
+        return ops.unpack_ncdhw(act, c, 0), ops.s2d_repack(act, cblk)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy, gs):
+        shape, dtype, c = ctx.meta
+        if gy is None and gs is None:
+            return None, None, None
+        out = torch.empty(shape, dtype=dtype, device=(gy if gy is not None else gs).device)
+        ops.seam_grad(gy.to(torch.float32).contiguous() if gy is not None else None, ops.as_act(gs) if gs is not None else None, out, c, shape[1:4])
+        return out, None, None
+
+
 # ====================================================================================== conv
 class ConvSpec:
     """Static description of one convolution layer (+ its packed-weight cache)."""

@@ -120,8 +120,27 @@ class bSSFPToDWITensorModel(nn.Module):
         return (self.fused_loss_heads and self.l1_fn is None and not self.extra_recon_terms
                 and all(t.is_cuda and t.dtype == torch.float32 for t in tensors))
 
+    def _gen_for_discr(self, x):
+        """``self.gen(x)`` on its way into the discriminator: the HIP generator then also hands over S(output) (Fn.GenOutFn)"""
+        if hasattr(self.gen, "emit_s2d") and next(self.gen.parameters()).is_cuda:
+            self.gen.emit_s2d = True
+            try:
+                return self.gen(x)
+            finally:
+                self.gen.emit_s2d = False
+        return self.gen(x)
+
+    @staticmethod
+    def _detach(y):
+        """``y.detach()`` that keeps the space-to-depth companion of a generator output"""
+        out = y.detach()
+        s = getattr(y, "_mi355_s2d", None)
+        if s is not None:
+            out._mi355_s2d = s.detach()
+        return out
+
     def _gen_step(self, x, y, logs, step_name="train"):
-        y_hat = self.gen(x)
+        y_hat = self._gen_for_discr(x)
         logits = self.discr(x, y_hat)
         if self._fused_losses(logits, y_hat, y):
             from .functional import GanGenLossFn
@@ -150,7 +169,7 @@ class bSSFPToDWITensorModel(nn.Module):
         return 2
 
     def _discr_step(self, x, y):
-        y_hat = self.gen(x).detach()
+        y_hat = self._detach(self._gen_for_discr(x))
         if self._discr_pair():
             both = self.discr.forward_pair(x, y_hat, y, stacked=self._fused_losses(x, y))
             if isinstance(both, torch.Tensor):                      # one pass over both inputs: fake first, then real

@@ -243,7 +243,7 @@ class Discriminator(_Mi355Module):
             split = self._split_first_block(x, y, x.shape[0])
             if split:
                 h = self._packed_x(x, split[2])                         # S(x): constant, packed once per training step
-                h1 = Fn.PackFn.apply(-split[3], self.compute_dtype, y)  # S(y): the part that changes (and may need a gradient)
+                h1 = self._s2d_of(y, split[3])                          # S(y): the part that changes (and may need a gradient)
             else:
                 h = Fn.PackFn.apply(-cp, self.compute_dtype, x, y)      # cat([x, y], 1) + layout + s2d
             for i, blk in enumerate(blocks):
@@ -279,6 +279,13 @@ class Discriminator(_Mi355Module):
         if not (ops.conv_k2_marches(x.shape[0], se, 8 * cpx, coutp) and ops.conv_k2_marches(n_grid, se, 8 * cpy, coutp)):
             return None
         return cx, cy, cpx, cpy
+
+    def _s2d_of(self, y, cpy):
+        """S(y) with cpy channels per block: the tensor the generator produced beside y (Fn.GenOutFn), or a pack of y"""
+        s = getattr(y, "_mi355_s2d", None)
+        if s is not None and s.dtype == self.compute_dtype and s.shape[4] == 8 * cpy and s.shape[0] == y.shape[0]:
+            return s
+        return Fn.PackFn.apply(-cpy, self.compute_dtype, y)
 
     def _packed_x(self, x, cpx):
         hit = Fn.PackMemo.get(x, -cpx, self.compute_dtype)
@@ -316,7 +323,11 @@ class Discriminator(_Mi355Module):
             h = self._packed_x(x, split[2])                         # ONE S(x) under both halves of the stacked S(y)
             h1 = Fn._new_s2d(ops.s2d_shape(2 * n, d, hh, w, split[3]), self.compute_dtype, x.device)
             for half, y in enumerate((y_a, y_b)):
-                ops.pack_ncdhw_s2d(y.detach().to(torch.float32).contiguous(), h1[half * n:(half + 1) * n], split[3], 0, split[3])
+                s = getattr(y, "_mi355_s2d", None)
+                if s is not None and s.dtype == self.compute_dtype and tuple(s.shape) == tuple(h1[half * n:(half + 1) * n].shape):
+                    h1[half * n:(half + 1) * n].copy_(s.detach())   # the generator already produced S(y) (Fn.GenOutFn)
+                else:
+                    ops.pack_ncdhw_s2d(y.detach().to(torch.float32).contiguous(), h1[half * n:(half + 1) * n], split[3], 0, split[3])
         else:
             h = Fn._new_s2d(ops.s2d_shape(2 * n, d, hh, w, cp), self.compute_dtype, x.device)
             x32 = x.detach().to(torch.float32).contiguous()
@@ -586,8 +597,14 @@ class Generator(_Mi355Module):
         self.blocks = nn.ModuleDict({"dwi-tensor": dwi_tensor_input, "pc-bssfp": bssfp_input,
                                      "bssfp": bssfp_input, "t1w": dwi_tensor_input, "unet": unet})
 
+    emit_s2d = False      # set by the training harness: also hand S(output) to the PatchGAN (Fn.GenOutFn), bf16 mode, even extents
+
     def forward(self, x):
         head = self.blocks[self.input_modality]
         a = head.forward_act(head._to_act(x))
         z = self.blocks["unet"].forward_act(a)
+        if self.emit_s2d and z.dtype == torch.bfloat16 and all(e % 2 == 0 for e in z.shape[1:4]):
+            y, s = Fn.GenOutFn.apply(z, 6, 8)
+            y._mi355_s2d = s
+            return y
         return Fn.UnpackFn.apply(z, 6)

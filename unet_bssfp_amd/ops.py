@@ -385,10 +385,23 @@ def border_sums(g: torch.Tensor, c: Optional[int] = None) -> torch.Tensor:
     return e
 
 
-def s2d_repack(x: torch.Tensor) -> torch.Tensor:
-    """plain activation (n, d, h, w, c) -> its space-to-depth tensor (n, d/2+1, h/2+1, w/2+1, 8c), same dtype."""
+def seam_grad(gy: Optional[torch.Tensor], gs: Optional[torch.Tensor], out: torch.Tensor, c: int, dims):
+    """out (NDHWC activation gradient) = gy (f32 NCDHW, or None) + un-space-to-depth(gs) (or None); channels >= c zero."""
+    require_cuda(gy, gs, out)
+    n, d, h, w, cp = out.shape
+    assert (d, h, w) == tuple(dims) and (gy is None or (gy.dtype == torch.float32 and gy.is_contiguous() and tuple(gy.shape) == (n, c, d, h, w)))
+    cblk = gs.shape[4] // 8 if gs is not None else 0
+    assert gs is None or (gs.dtype == out.dtype and tuple(gs.shape[:4]) == tuple(s2d_shape(n, d, h, w, cblk)[:4]))
+    _lib.check(_lib.load().mi355_seam_grad(_ptr(gy), _ptr(gs), act_ld(gs) if gs is not None else 0, cblk, out.data_ptr(), act_ld(out), cp,
+                                           n, c, d, h, w, _DT[out.dtype], _stream()), "seam_grad")
+    return out
+
+
+def s2d_repack(x: torch.Tensor, c: Optional[int] = None) -> torch.Tensor:
+    """plain activation (n, d, h, w, cp) -> the space-to-depth tensor of its first c channels (n, d/2+1, h/2+1, w/2+1, 8c), same dtype."""
     require_cuda(x)
-    n, d, h, w, c = x.shape
+    n, d, h, w, cp = x.shape
+    c = cp if c is None else c
     out = torch.empty(s2d_shape(n, d, h, w, c), dtype=x.dtype, device=x.device)
     _lib.check(_lib.load().mi355_s2d_repack(x.data_ptr(), act_ld(x), out.data_ptr(), act_ld(out), n, d, h, w, c, _DT[x.dtype], _stream()),
                "s2d_repack")
