@@ -193,3 +193,27 @@ def test_weight_pack_index_algebra_matches_conv_definitions():
         wt = gather(wd, cout, cin, 1, 8, cout * 8, (4, 2, 1), cls, (0, 0, 0))
         out[:, cls[0]::2, cls[1]::2, cls[2]::2] = conv_taps(xd, wt, 1, (0, 0, 0), (3, 3, 3))
     np.testing.assert_allclose(out, refd, rtol=1e-10, atol=1e-10)
+
+
+def test_lds_dma_kernels_contain_no_compiler_generated_m0_use():
+    """common.h: dma_lds_b128 overwrites m0 inside an asm statement and cannot declare it (hipcc rejects the clobber).  That is safe
+    only while the compiler itself neither sets nor reads m0 in those kernels: no movrel / s_set_gpr_idx (dynamically indexed
+    register arrays), no LDS-direct / addtid / GWS / s_sendmsg use, no m0 operand other than the statement's own `s_mov_b32 m0`.
+    The build emits the device ISA of the two sources that hold such kernels (csrc/Makefile: *.gfx950.s); this scans it."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "unet_bssfp_amd", "csrc", "*.gfx950.s")))
+    if not files:
+        pytest.skip("device ISA listings not built (make -C unet_bssfp_amd/csrc)")
+    forbidden = re.compile(r"\b(v_movrel\w*|s_set_gpr_idx\w*|ds_\w*addtid\w*|ds_gws\w*|s_sendmsg\w*|lds_direct\w*|v_interp\w*|s_movrel\w*)\b")
+    dma = 0
+    for f in files:
+        for ln, line in enumerate(open(f), 1):
+            code = line.split(";")[0]
+            if not code.strip() or code.lstrip().startswith((".", "//")):
+                continue
+            assert not forbidden.search(code), f"{os.path.basename(f)}:{ln}: {code.strip()}"
+            if re.search(r"\bm0\b", code):
+                assert re.match(r"\s*s_mov_b32\s+m0\s*,", code), f"{os.path.basename(f)}:{ln}: m0 used by the compiler: {code.strip()}"
+            dma += bool(re.search(r"buffer_load_dwordx4\b.*\blds\b", code))
+    assert dma > 100, dma            # the listings really are those of the LDS-DMA kernels

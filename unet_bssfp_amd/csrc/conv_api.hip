@@ -189,7 +189,7 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
         const int f = forced_shape();
         const long long nv = (long long)d->n * d->di * d->hi * d->wi;
         const bool ru_ok = nv * d->ld0 * 2 < (1ll << 31) && nv * (d->c1 ? d->ld1 : 0) * 2 < (1ll << 31) &&
-                           (long long)d->n * d->dy * d->hy * d->wy * d->ldy * (d->y_f32 ? 4 : 2) < (1ll << 31);      // 32-bit byte offsets
+                           (long long)d->n * d->dy * d->hy * d->wy * d->ldy * 2 < (1ll << 31);                       // 32-bit byte offsets
         const bool big = count(6, p->ct) >= 1024;
         const long long c9 = count(9, p->ct);
         int pick = (p->ct == 1 ? c9 >= 1024 : c9 >= 512) ? 9 : (big ? 6 : 0);
@@ -294,10 +294,7 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
     p->shape = 0;
   }
   MI355_REQUIRE(p->halo || (!d->addend && !d->y_f32 && !d->d2s), "conv: addend / y_f32 / d2s need the marching k2 plan");
-  // f32 output on bf16 operands: the marching k2 kernel, and the marching 3x3x3 kernel of the <= 32-input-channel layers
-  MI355_REQUIRE(!d->y_f32 || (p->halo && (p->shape == 14 || (p->shape == 10 && d->dtype == MI355_DT_BF16 && (d->cstore & 15) == 0 &&
-                                                                   !d->bias && !d->stats_part))),
-                "conv: y_f32 is implemented by the marching k2 kernel and by conv_march_kernel (bf16, <= 32 input channels)");
+  MI355_REQUIRE(!d->y_f32 || (p->halo && p->shape == 14), "conv: y_f32 is implemented by the marching k2 kernel");
   MI355_REQUIRE(d->dtype != MI355_DT_FP8 || (p->halo && p->shape == 10),
                 "conv: the fp8 path covers 3x3x3 stride-1 layers with 32 input channels in one source and a plain output grid");
   MI355_REQUIRE(p->tiles < (1ll << 31), "conv: too many tiles");
@@ -416,13 +413,11 @@ int launch(const mi355_conv_desc* d, const Plan& p, hipStream_t st) {
       } else if (p.shape == 10) {
         if constexpr (sizeof(T) == 2) {
           static const int once = [] {
-            return raise_lds((const void*)conv_march_kernel<false>, MarchCfg<false>::LDS) | raise_lds((const void*)conv_march_kernel<true>, MarchCfg<true>::LDS) |
-                   raise_lds((const void*)conv_march_kernel<false, true>, MarchCfg<false>::LDS);
+            return raise_lds((const void*)conv_march_kernel<false>, MarchCfg<false>::LDS) | raise_lds((const void*)conv_march_kernel<true>, MarchCfg<true>::LDS);
           }();
           if (once) { mi355_set_error("conv_march: cannot raise the dynamic LDS limit to %d bytes (hip error %d)", MarchCfg<false>::LDS, once); return MI355_ERR_HIP; }
           MarchArgs m{p.seg_len, p.nseg, p.tiles_h, p.tiles_w, d->q_amax_x, d->q_amax_w};
           if (d->dtype == MI355_DT_FP8) conv_march_kernel<true><<<grid, block, MarchCfg<true>::LDS, st>>>(a, m);
-          else if (d->y_f32) conv_march_kernel<false, true><<<grid, block, MarchCfg<false>::LDS, st>>>(a, m);
           else conv_march_kernel<false><<<grid, block, MarchCfg<false>::LDS, st>>>(a, m);
         }
       } else if (p.shape == 11) {

@@ -60,10 +60,7 @@ struct MarchArgs { int seg_len, nseg, tiles_h, tiles_w; const float* amax_x; con
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
-// YF32: the output tensor is f32 (4-byte elements, ldy in elements) instead of bf16 and holds the RAW accumulators (no bias,
-// no statistics): the skip part of a concatenated convolution on its way into another launch's accumulators
-// (UpCatConvFn) -- no rounding between the two partial sums.
-template <bool F8, bool YF32 = false>
+template <bool F8>
 __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, const MarchArgs m) {
   using T = bf16_t;                                                  // output element
   using Cfg = MarchCfg<F8>;
@@ -203,25 +200,17 @@ __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, co
       }
     }
   };
-  // ---- epilogue of one finished output plane q (generic form): bf16, two 16-byte stores per lane and row (f32: four)
+  // ---- epilogue of one finished output plane q (generic form): bf16, two 16-byte stores per lane and row
   auto store_plane = [&](f32x16 (&s)[4], int q) __attribute__((always_inline)) {
 #pragma unroll
     for (int row = 0; row < 4; ++row) {
       const int gh = h0 + 4 * wave + row;
       if (gh >= a.ho) break;                                          // wave-uniform
-      if constexpr (YF32) {
-        float* dst = reinterpret_cast<float*>(a.y) + ((((long long)tn * a.dy + q) * a.hy + gh) * a.wy + w0 + r) * a.ldy + cch;
-#pragma unroll
-        for (int i4 = 0; i4 < 4; ++i4)
-          if (vox_ok && cch + 4 * i4 + 4 <= a.cstore)
-            *reinterpret_cast<float4*>(dst + 4 * i4) = make_float4(s[row][4 * i4], s[row][4 * i4 + 1], s[row][4 * i4 + 2], s[row][4 * i4 + 3]);
-      } else {
       T* dst = reinterpret_cast<T*>(a.y) + ((((long long)tn * a.dy + q) * a.hy + gh) * a.wy + w0 + r) * a.ldy + cch;
       uint32_t w[8];
       pack_row(s[row], w, vox_ok);
       if (st0) *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
       if (st1) *reinterpret_cast<uint4*>(dst + 8) = make_uint4(w[4], w[5], w[6], w[7]);
-      }
     }
   };
   auto init_row = [&](f32x16& s) __attribute__((always_inline)) {    // first contribution to an output row: C = 0
@@ -307,9 +296,8 @@ __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, co
   // ---- the steady-state step (all three output planes inside the segment, footprint inside the volume) as ONE basic
   //      block: the next plane's LDS-DMA, 3 x NG chained fragment groups (kd = 2, 1, 0) and the epilogue of the plane that
   //      kd = 2 completes (buffer stores: lanes that must not store get an out-of-range offset, no branch).
-  constexpr int YB = YF32 ? 4 : 2;                                            // bytes per output element
-  const auto rsy = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (int)((((long long)a.n * a.dy * a.hy * a.wy - 1) * a.ldy + a.cstore) * YB), 0x00020000);
-  const int yrow = ((4 * wave) * a.wy + w0 + r) * a.ldy * YB + cch * YB;      // byte offset of this lane's voxel in row 0 of a plane's footprint
+  const auto rsy = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (int)((((long long)a.n * a.dy * a.hy * a.wy - 1) * a.ldy + a.cstore) * 2), 0x00020000);
+  const int yrow = ((4 * wave) * a.wy + w0 + r) * a.ldy * 2 + cch * 2;        // byte offset of this lane's voxel in row 0 of a plane's footprint
   // The next plane's NI copies are issued ONE AT A TIME between the fragment groups (fenced: nothing is scheduled across a
   // copy): issued together at the top of the step they cost the wave their whole issue time with the matrix pipe idle; behind
   // a group, a copy's issue runs under the MFMA in flight.  The table entry of a copy is read one group ahead.  The finished
@@ -320,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, co
     const bool pin = p + 1 >= 0 && p + 1 < a.di;
     const int soff = pin ? (tn * a.di + p + 1) * plane_stride : 0;
     char* const dst = smem + ((p + 1) & 1) * Cfg::PLANE + wave * 1024;
-    const int ybase = ((tn * a.dy + (p - 1)) * a.hy + h0) * a.wy * a.ldy * YB;
+    const int ybase = ((tn * a.dy + (p - 1)) * a.hy + h0) * a.wy * a.ldy * 2;
     Group g[2];
     load_group(g[0], pl, 2, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
@@ -346,26 +334,15 @@ __global__ __launch_bounds__(256, 1) void conv_march_kernel(const ConvArgs a, co
       if (gi >= NG && gi < NG + 4) {                                    // output plane p - 1 is complete: row gi - NG
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         const int row = gi - NG;
+        uint32_t w[8];
+        pack_row(s_m1[row], w, true);
         // (the plane's base goes into the VECTOR offset, soffset = 0: with a register soffset hipcc places a VALU write
         //  of the store's data registers right behind a 16-byte store -- on gfx950 the store then read the NEW values
         //  in its last lanes; with a constant soffset the compiler's own hazard rule keeps the wait state)
-        const int off = ybase + yrow + row * a.wy * a.ldy * YB;
-        if constexpr (YF32) {
-          // (the partial sums carry no bias and no statistics: the launch that completes them adds both)
-          const int offv = st1 ? off : (int)0x80000000;
-#pragma unroll
-          for (int i4 = 0; i4 < 4; ++i4) {
-            const u32x4 v = {__float_as_uint(s_m1[row][4 * i4]), __float_as_uint(s_m1[row][4 * i4 + 1]), __float_as_uint(s_m1[row][4 * i4 + 2]),
-                             __float_as_uint(s_m1[row][4 * i4 + 3])};
-            __builtin_amdgcn_raw_buffer_store_b128(v, rsy, offv + 16 * i4, 0, 0);
-          }
-        } else {
-        uint32_t w[8];
-        pack_row(s_m1[row], w, true);
+        const int off = ybase + yrow + row * a.wy * a.ldy * 2;
         u32x4 lo = {w[0], w[1], w[2], w[3]}, hi = {w[4], w[5], w[6], w[7]};
         __builtin_amdgcn_raw_buffer_store_b128(lo, rsy, st0 ? off : (int)0x80000000, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(hi, rsy, st1 ? off + 16 : (int)0x80000000, 0, 0);
-        }
       }
 #endif
       // this group's MFMAs with the next group's reads between them (see pin_pipeline)

@@ -290,7 +290,8 @@ class Discriminator(_Mi355Module):
     def _packed_x(self, x, cpx):
         hit = Fn.PackMemo.get(x, -cpx, self.compute_dtype)
         if hit is None:
-            hit = Fn.PackFn.apply(-cpx, self.compute_dtype, x.detach())
+            plain = Fn.PackMemo.get(x, cpx, self.compute_dtype)     # the generator packed the same batch (NDHWC): re-lay it out
+            hit = ops.s2d_repack(plain) if plain is not None else Fn.PackFn.apply(-cpx, self.compute_dtype, x.detach())
             Fn.PackMemo.put(x, -cpx, self.compute_dtype, hit)
         return hit
 

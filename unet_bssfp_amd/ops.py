@@ -243,12 +243,6 @@ def conv_num_tiles(x0, x1, wp, coutp, ks, stride, pad, out, grid, os=1, ooff=(0,
     return tiles.value, tps.value
 
 
-def conv_plan_ok(x0, x1, wp, coutp, ks, stride, pad, out, grid) -> bool:
-    """Does mi355_conv_fwd have a plan for this launch (asked before choosing an f32 `out` on bf16 operands)?"""
-    d = _conv_desc(x0, x1, wp, coutp, None, ks, stride, pad, out, grid, 1, (0, 0, 0), None)
-    return _lib.load().mi355_conv_plan_id(C.byref(d)) > 0
-
-
 def conv_k2_marches(n: int, s_extents, c_in: int, coutp: int) -> bool:
     """Would a bf16 dense k2 (padding 0) convolution of an (n, *s_extents, c_in) space-to-depth tensor to coutp channels run
     on conv_march2_kernel -- the plan that honours `addend` / an f32 output?  (Asked before a layer is split.)"""
