@@ -483,10 +483,12 @@ int mi355_cast_fp8(const void* src, int32_t ld_src, int32_t c, int64_t rows, int
 /* Delayed scaling (the producer of an operand cannot know its amax before it has written it): the cast uses amax[0], the
  * amax gathered during the PREVIOUS training step, and raises amax_next[0] (may be NULL) to max |src|; values beyond
  * 2 * amax saturate at +-448.  mi355_fp8_scale_roll: table[n][2] = (amax in use, amax being gathered); once per step
- * in-use = gathered where gathered > 0, gathered = 0.  The first step of a layer uses mi355_amax_act + mi355_cast_fp8. */
+ * in-use = gathered where gathered > 0, gathered = 0.  The first step of a layer uses mi355_amax_act + mi355_cast_fp8.
+ * sat (int32[n] or NULL): sat[i] += 1 when the step that ends here saturated in slot i (gathered > 2 * in-use: some value
+ * clamped at +-448) -- an overflow record without counters in the cast kernels. */
 int mi355_cast_fp8_delayed(const void* src, int32_t ld_src, int32_t c, int64_t rows, int32_t src_dtype, const float* amax,
                            float* amax_next, void* dst, int32_t ld_dst, void* stream);
-int mi355_fp8_scale_roll(float* table, int32_t n, void* stream);
+int mi355_fp8_scale_roll(float* table, int32_t n, int32_t* sat, void* stream);
 int mi355_fp8_selftest(float* out_1024, void* stream);
 
 #ifdef __cplusplus

@@ -161,6 +161,8 @@ def test_fp8_gan_step_at_config5_size_160(hip):
     state = copy.deepcopy((gen.state_dict(), discr.state_dict()))
     batch = synthetic_batch(1, 160, seed=77, device=DEV)
     logs, params, plans = {}, {}, []
+    from unet_bssfp_amd.functional import Fp8Scales as _Scales
+    sat0 = _Scales.saturated_steps(DEV)
     for mode in ("bf16", "fp8", "fp8_again"):
         g, d = M.Generator("bssfp", dropout=0.0), M.Discriminator("bssfp")
         g.load_state_dict(state[0])
@@ -204,6 +206,9 @@ def test_fp8_gan_step_at_config5_size_160(hip):
         assert np.isfinite(got)
         assert abs(got - ref) <= (5e-3 if "discr" not in k else 2e-2) * abs(ref), (k, got, ref)
     assert logs["fp8"] == logs["fp8_again"] and logs["fp8_step1"] == logs["fp8_again_step1"]
+    # delayed scaling clamps what exceeds twice the previous step's amax: the overflow record must be empty here
+    from unet_bssfp_amd.functional import Fp8Scales
+    assert Fp8Scales.saturated_steps(DEV) == sat0, (Fp8Scales.saturated_steps(DEV), sat0)
     assert abs(logs["fp8_step1"]["train_gen_loss_recon_L1"] - logs["fp8"]["train_gen_loss_recon_L1"]) < 0.1 * logs["fp8"]["train_gen_loss_recon_L1"]
     assert all(torch.equal(a, b) for a, b in zip(params["fp8"], params["fp8_again"]))
     assert all(torch.isfinite(p).all() for p in params["fp8"])
@@ -302,3 +307,33 @@ def test_fp8_delayed_scaling_steps_producer_side_equals_cast_side_and_graph_repl
     torch.cuda.synchronize()
     for (name, q), p in zip(graphed.named_parameters(), results["producer"]):
         assert torch.equal(p, q), name
+
+
+def test_fp8_delayed_scaling_records_saturation(hip):
+    """delayed scaling saturates silently (values beyond twice the previous step's amax clamp at +-448).  Every cast
+    kernel gathers the step's amax anyway, so the roll that ends a step knows: gathered > 2 x in-use <=> something clamped; it
+    raises the slot's record (Fp8Scales.Slot.sat, summed by Fp8Scales.saturated_steps)."""
+    from unet_bssfp_amd import ops
+    from unet_bssfp_amd.functional import Fp8Scales
+    dev = torch.device(DEV)
+    before = Fp8Scales.saturated_steps(dev)
+    slot = Fp8Scales.slot(dev)
+    x = torch.randn(1, 8, 8, 32, 32, device=DEV).to(torch.bfloat16)
+    # step 1: no history -> in-step amax (cannot saturate)
+    ops.amax_act(x, out=slot.use)
+    x8 = ops.cast_fp8(x, slot.use, slot.next)
+    slot.touched = True
+    Fp8Scales.advance(dev)
+    assert int(slot.sat) == 0 and float(slot.use) > 0
+    # step 2: the tensor grew 1.5x: inside the head-room of delayed scaling (e4m3 holds 448, the scale maps amax to 224)
+    x8 = ops.cast_fp8(x * 1.5, slot.use, slot.next)
+    slot.touched = True
+    Fp8Scales.advance(dev)
+    assert int(slot.sat) == 0
+    # step 3: it grew 3x against the amax in use: values clamp, and the roll says so
+    x8 = ops.cast_fp8(x * 4.5, slot.use, slot.next)
+    assert int(x8.view(torch.uint8).max()) >= 0x7E                    # 448 = 0x7E in e4m3 (sign bit aside)
+    slot.touched = True
+    Fp8Scales.advance(dev)
+    assert int(slot.sat) == 1
+    assert Fp8Scales.saturated_steps(dev) == before + 1

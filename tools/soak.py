@@ -35,7 +35,8 @@ bad = [n for n, p in model.named_parameters() if not torch.isfinite(p).all()]
 print(f"{a.steps} steps in {dt:.1f} s ({dt / a.steps * 1e3:.2f} ms per step incl. the input copies); non-finite parameters: {bad or 'none'}")
 if a.dtype == "fp8":
     from unet_bssfp_amd.functional import Fp8Scales
-    for table, slots in Fp8Scales._chunks.get(dev, []):
+    for table, slots, sat in Fp8Scales._chunks.get(dev, []):
         t = table[: len(slots)].cpu()
         print("delayed-scaling slots (amax in use):", " ".join(f"{float(v):.3g}" for v in t[:, 0]))
+        print("steps in which a slot saturated (a value clamped at +-448):", " ".join(str(int(v)) for v in sat[: len(slots)].cpu()))
 assert not bad

@@ -132,7 +132,7 @@ _SIGNATURES = {
     "mi355_amax_act": (C.c_int, [_vp, _i32, _i32, _i64, _i32, _vp, _vp]),
     "mi355_cast_fp8": (C.c_int, [_vp, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _vp]),
     "mi355_cast_fp8_delayed": (C.c_int, [_vp, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _i32, _vp]),
-    "mi355_fp8_scale_roll": (C.c_int, [_vp, _i32, _vp]),
+    "mi355_fp8_scale_roll": (C.c_int, [_vp, _i32, _vp, _vp]),
     "mi355_fp8_selftest": (C.c_int, [_vp, _vp]),
 }
 

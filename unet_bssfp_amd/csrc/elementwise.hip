@@ -1886,10 +1886,14 @@ __global__ __launch_bounds__(256) void cast_fp8_kernel(const T* __restrict__ x, 
   if (next) amax_commit(m, next);
 }
 // delayed scaling: the amax gathered during a step becomes the scale of the next one
-__global__ void fp8_scale_roll_kernel(float* __restrict__ table, int n) {
+// sat (optional, int32 per slot): raised when the step that ends here SATURATED in that slot -- a value clamps at +-448 exactly
+// when |value| * 224 / amax_in_use > 448, i.e. when the amax gathered during the step exceeds twice the amax in use (every
+// kernel that casts an operand also gathers its maximum), so the roll sees it without any counter in the cast kernels
+__global__ void fp8_scale_roll_kernel(float* __restrict__ table, int n, int* __restrict__ sat) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float nx = table[2 * i + 1];
+  const float use = table[2 * i], nx = table[2 * i + 1];
+  if (sat && use > 0.f && nx > 2.f * use) sat[i] += 1;
   if (nx > 0.f) table[2 * i] = nx;
   table[2 * i + 1] = 0.f;
 }
@@ -1951,9 +1955,9 @@ int mi355_cast_fp8(const void* src, int32_t ld_src, int32_t c, int64_t rows, int
   return mi355_cast_fp8_delayed(src, ld_src, c, rows, src_dtype, amax, nullptr, dst, ld_dst, stream);
 }
 
-int mi355_fp8_scale_roll(float* table, int32_t n, void* stream) {
+int mi355_fp8_scale_roll(float* table, int32_t n, int32_t* sat, void* stream) {
   MI355_REQUIRE(table && n > 0, "fp8_scale_roll: bad argument");
-  hipLaunchKernelGGL(fp8_scale_roll_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, (int)n);
+  hipLaunchKernelGGL(fp8_scale_roll_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, (int)n, (int*)sat);
   return mi355_check_launch("fp8_scale_roll");
 }
 

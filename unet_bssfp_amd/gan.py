@@ -516,7 +516,7 @@ class GraphedTrainingStep:
         if fn is None:
             return
         for chunks in fn.Fp8Scales._chunks.values():
-            for _table, slots in chunks:
+            for _table, slots, _sat in chunks:
                 bad = [i for i, s in enumerate(slots) if s.touched and not s.primed]
                 if bad:
                     raise RuntimeError(f"fp8 delayed-scaling slots {bad} are in use but not primed at capture time")

@@ -431,11 +431,13 @@ def cast_fp8(x: torch.Tensor, amax: torch.Tensor, amax_next: Optional[torch.Tens
     return out
 
 
-def fp8_scale_roll(table: torch.Tensor, n: int):
-    """table f32 [rows][2] = (amax in use, amax being gathered): the first n rows start a new training step."""
-    require_cuda(table)
+def fp8_scale_roll(table: torch.Tensor, n: int, sat: Optional[torch.Tensor] = None):
+    """table f32 [rows][2] = (amax in use, amax being gathered): the first n rows start a new training step.
+    sat (int32 [rows]): += 1 per slot whose ending step saturated (a value clamped at +-448: gathered amax > 2 x the one in use)."""
+    require_cuda(table, sat)
     assert table.dtype == torch.float32 and table.is_contiguous() and table.shape[1] == 2 and 0 < n <= table.shape[0]
-    _lib.check(_lib.load().mi355_fp8_scale_roll(table.data_ptr(), n, _stream()), "fp8_scale_roll")
+    assert sat is None or (sat.dtype == torch.int32 and sat.is_contiguous() and sat.numel() >= n)
+    _lib.check(_lib.load().mi355_fp8_scale_roll(table.data_ptr(), n, _ptr(sat), _stream()), "fp8_scale_roll")
 
 
 def conv_fp8_layer_ok(n: int, d: int, h: int, w: int, c_in: int, c_out: int) -> bool:
