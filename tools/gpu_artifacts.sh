@@ -1,10 +1,17 @@
 #!/bin/bash
-# usage: tools/gpu_artifacts.sh <tag>   -- the measurement artefacts of a round (copied from gpurun_out/ into profiles/ afterwards)
+# usage: tools/gpu_artifacts.sh <tag> [a|b]  -- the measurement artefacts of a round (copied from gpurun_out/ into profiles/ afterwards);
+# part a = PMC traffic passes + kernel statistics + replay trace + PMC of the marching kernels, part b = the bench lines (a gpurun call is
+# limited to 20 minutes: two calls); no part = both
 tag=$1
+part=${2:-ab}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
+if [[ $part == *a* ]]; then
 bash tools/pmc_traffic.sh $tag 128 bf16 > gpurun_out/${tag}_pmc_traffic.log 2>&1; echo "traffic rc=$?"; tail -3 gpurun_out/${tag}_pmc_traffic.log
 cp profiles/${tag}_bf16_128_traffic.json profiles/${tag}_bf16_128_pmc_step_traffic.txt gpurun_out/ 2>/dev/null
+bash tools/pmc_traffic.sh $tag 160 fp8 > gpurun_out/${tag}_pmc_traffic_fp8_160.log 2>&1; echo "traffic fp8 160 rc=$?"; tail -3 gpurun_out/${tag}_pmc_traffic_fp8_160.log
+cp profiles/${tag}_fp8_160_traffic.json profiles/${tag}_fp8_160_pmc_step_traffic.txt gpurun_out/ 2>/dev/null
+fi
 run() { name=$1; shift; timeout -k 10 400 "$@" > gpurun_out/${tag}_bench_$name.json 2> gpurun_out/${tag}_bench_$name.err; python - <<PY
 import json
 try:
@@ -13,13 +20,17 @@ try:
 except Exception as e: print("$name", "ERR", e); print(open("gpurun_out/${tag}_bench_$name.err").read()[-600:])
 PY
 }
+if [[ $part == *b* ]]; then
 run bf16_default python bench.py
 run bf16_gen_only python bench.py --workload gen_only --no-cpu-baseline
 run bf16_160 python bench.py --size 160 --steps 100 --no-cpu-baseline
 run fp8_160 python bench.py --size 160 --steps 100 --dtype fp8 --no-cpu-baseline
+run bf16_8x64 python bench.py --size 64 --batch 8 --steps 100 --no-cpu-baseline
 run bf16_fresh_batch python bench.py --fresh-batch --no-cpu-baseline
 run bf16_force_collectives python bench.py --force-collectives --no-cpu-baseline
 run bf16_2rank_gloo python bench.py --gpus 2 --backend gloo --steps 20 --no-cpu-baseline
+fi
+if [[ $part == *a* ]]; then
 # kernel stats of the eager step
 OUT=$ROOT/gpurun_out/${tag}_stats; mkdir -p $OUT
 ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o p -- python3 $ROOT/bench.py --steps 40 --warmup 5 --settle-s 0 --no-graph --no-cpu-baseline --no-probe > $OUT/run.log 2>&1 )
@@ -38,3 +49,4 @@ for k in ("marchg", "march"):
         print(k, "kernel duration in the SQ1 pass: mean %.1f us over %d dispatches" % (sum(d) / len(d), len(d)))
     except Exception as e: print(k, "ERR", e)
 PY
+fi
