@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 mkdir -p tools/_build
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -DMI355_DIAG $MI355_DIAG_FLAGS"
 OBJS=""
-for f in runtime conv_api wgrad elementwise dti patches metrics augment; do
+for f in runtime conv_api wgrad elementwise upcat dti patches metrics augment; do
   /opt/rocm/bin/hipcc $FLAGS -c unet_bssfp_amd/csrc/$f.hip -o tools/_build/$f.o &
   OBJS="$OBJS tools/_build/$f.o"
 done
