@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 [ -f tools/_build/runtime.o ] || bash tools/build_diag.sh
 OTHERS=""
-for f in runtime wgrad elementwise dti patches metrics augment; do OTHERS="$OTHERS tools/_build/$f.o"; done
+for f in runtime wgrad elementwise upcat dti patches metrics augment; do OTHERS="$OTHERS tools/_build/$f.o"; done
 for spec in "$@"; do
   name=${spec%%=*}; flags=${spec#*=}
   ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DMI355_DIAG $flags -c unet_bssfp_amd/csrc/conv_api.hip -o tools/_build/conv_api_$name.o &&
