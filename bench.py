@@ -84,6 +84,7 @@ def parse():
                     help="world size > 1: broadcast rank 0's BatchNorm running statistics before every k-th step "
                          "(DDP's broadcast_buffers=True, src/train.py:30; 0 = never)")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch (--gpus N without torch.distributed.run): rendezvous port (0 = pick a free one)")
+    ap.add_argument("--eager-final-dx", action="store_true", help="developer A/B: the final 1x1x1 convolution writes its data gradient (one launch, 134 MB) instead of leaving it to the norm backward kernels (Fn.LazyDx); reported")
     ap.add_argument("--separate-colsum", action="store_true", help="developer A/B: transposed-conv bias gradients by a separate pass over the gradient instead of the producing launch's statistics; reported")
     ap.add_argument("--composed-losses", action="store_true", help="developer A/B: BCE / L1 loss heads as composed torch ops instead of the one-launch kernels; reported")
     ap.add_argument("--side-stream", action="store_true", help="developer A/B: weight gradients of the small layers on a second stream (measured slower); reported")
@@ -417,6 +418,10 @@ def main():
         from unet_bssfp_amd import functional as _Fn
         _Fn.SideStream.allowed = True
         nondefault["side_stream"] = True
+    if a.eager_final_dx:
+        from unet_bssfp_amd import functional as _Fn3
+        _Fn3.LazyDx.enabled = False
+        nondefault["eager_final_dx"] = True
     if a.separate_colsum:
         from unet_bssfp_amd import functional as _Fn2
         _Fn2.ColSumSide.enabled = False

@@ -292,6 +292,17 @@ typedef struct mi355_normact_desc {
    * mi355_cast_fp8 makes of the stored bf16 tensor -- one byte per channel, row stride ld8 bytes, and raises q_next[0] to
    * max |a| (|dz|), the scale of the NEXT step (mi355_fp8_scale_roll).  bf16, c == 32, plain layouts only.  NULL: off. */
   void* q8; int32_t ld8; const float* q_use; float* q_next;
+  /* optional, backward (bwd_reduce / bwd_apply, bf16): `da` is NOT materialised -- it is the data gradient of the 1x1x1 convolution
+   * that consumed a (the U-Net's final convolution, src/model.py:22-28 via MONAI BasicUNet.final_conv):
+   * da[row][ch] = bf16(sum_{k < gk} gz[row][k] * bf16(gw[k * gw_ld + ch])); gz = gradient of that convolution's output, rows of ldgz >= 8
+   * elements of `dtype` (gk <= 8 real channels first), gw = its f32 master weights [gk][gw_ld] (channels >= gw_ld: zero).
+   * `da` must be NULL.  Saves the data-gradient launch (a 134-MB write at 128^3) and 100 MB of reads in each backward pass. */
+  const void* gz; int32_t ldgz; const float* gw; int32_t gw_ld; int32_t gk;
+  /* optional, forward (bf16, c = 32, plain layout, no q8): the same 1x1x1 convolution evaluated in the pass that writes a, on the
+   * rounded bf16 values: fy[row][k] = bf16(sum_ch a[row][ch] * bf16(gw[k * gw_ld + ch]) + fbias[k]) for k < gk, zero for gk <= k < fcp
+   * (rows of ldfy elements); skip_a = 1: a itself is not stored (a no-grad pass whose only consumer of a is that convolution).
+   * Saves the convolution's launch and its 134-MB read of a at 128^3. */
+  void* fy; int32_t ldfy; int32_t fcp; const float* fbias; int32_t skip_a;
 } mi355_normact_desc;
 int mi355_normact_fwd(const mi355_normact_desc* d, void* stream);
 int mi355_normact_bwd_reduce(const mi355_normact_desc* d, void* stream);

@@ -914,3 +914,74 @@ def test_generator_output_seam_equals_unpack_add_pack(hip, which):
     ref = ops.new_act(n, *sp, 16, dtype, DEV)
     ops.pack_ncdhw(total.contiguous(), ref, 0, 16)
     assert torch.equal(z.grad, ref)
+
+
+@pytest.mark.parametrize("drop_p", [0.0, 0.05])
+def test_norm_backward_forms_the_final_convs_data_gradient_itself(hip, drop_p):
+    """mi355_normact_bwd_reduce / _apply with gz / gw (Fn.LazyDx): the data gradient of the 1x1x1 convolution that consumed a
+    (BasicUNet.final_conv, src/model.py:22-28) is formed per row inside the norm backward kernels instead of being written by one
+    launch and read by two.  Against the explicit path on da = bf16(gz @ W) (torch): dz within one bf16 ulp of the values (the
+    two matmuls sum in different orders: a rounding of da can flip), affine gradients at the f32-sum bound; and through
+    autograd (ConvFn(lazy_dx) -> NormActFn) against the unfused graph."""
+    from unet_bssfp_amd import functional as Fn, ops
+    g = torch.Generator().manual_seed(23)
+    n, c, sp, k = 2, 32, (8, 12, 32), 6
+    dt = torch.bfloat16
+    z = to_act(q(torch.randn(n, c, *sp, generator=g) * 1.5 + 0.3, dt), dt)
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).to(DEV), (torch.rand(c, generator=g) - 0.5).to(DEV)
+    w = (torch.randn(k, c, 1, 1, 1, generator=g) * 0.2).to(DEV)
+    gz = to_act(q(torch.randn(n, 16, *sp, generator=g) * 0.1, dt), dt)
+    gz[..., k:] = 0
+    rows = sp[0] * sp[1] * sp[2]
+    part, ppg = ops.channel_stats(z, n)
+    mean, rstd = ops.norm_finalize(part, ppg, n, c, rows, None, 1e-5, None, None, 0.1, n_real=0)
+    seed_t = Fn.DropoutState.base(DEV) if drop_p > 0 else None
+    da = (gz[..., :k].float() @ w.reshape(k, c).to(dt).float()).to(dt).contiguous()     # (the kernels round W to bf16, like a packed weight)
+    dz_e, dg_e, db_e = ops.normact_bwd(z, da, n, mean, rstd, gamma, beta, 0.1, drop_p, 5, True, True, seed_t=seed_t)
+    dz_i, dg_i, db_i = ops.normact_bwd(z, None, n, mean, rstd, gamma, beta, 0.1, drop_p, 5, True, True, seed_t=seed_t,
+                                       implicit=(gz, w))
+    torch.cuda.synchronize()
+    e, i = dz_e.float(), dz_i.float()
+    # a flipped rounding of one da element moves dz by rstd * gamma * ulp(da): bounded by 2^-7 of the largest |da| * rstd * gamma
+    bound = 2.0 ** -7 * float(da.float().abs().max()) * float((rstd.max() * gamma.max()))
+    assert float((e - i).abs().max()) <= bound, (float((e - i).abs().max()), bound)
+    assert float((e - i).abs().mean()) <= 1e-2 * float(e.abs().mean())
+    close_f32_sum(dg_i.cpu(), dg_e.cpu(), "dgamma")
+    close_f32_sum(db_i.cpu(), db_e.cpu(), "dbeta")
+
+    # forward: the same convolution evaluated by the launch that writes a (ops.normact_fwd, final=), with and without storing a
+    fb = (torch.randn(k, generator=g) * 0.3).to(DEV)
+    a_ref = ops.normact_fwd(z, n, mean, rstd, gamma, beta, 0.1, drop_p, 5, seed_t=seed_t)
+    y_ref = (a_ref.float() @ w.reshape(k, c).to(dt).float().t() + fb).to(dt)
+    for skip in (False, True):
+        y = torch.full((n, *sp, 16), float("nan"), dtype=dt, device=DEV)
+        a2 = ops.normact_fwd(z, n, mean, rstd, gamma, beta, 0.1, drop_p, 5, seed_t=seed_t, final=(w, fb, y), skip_a=skip)
+        torch.cuda.synchronize()
+        if not skip:
+            assert torch.equal(a2, a_ref)
+        assert float(y[..., k:].float().abs().max()) == 0.0
+        d = (y[..., :k].float() - y_ref.float()).abs()
+        assert bool((d <= 2.0 ** -7 * y_ref.float().abs() + 1e-6).all()), float(d.max())
+        assert float((d > 0).float().mean()) < 0.05          # (a different summation order: rare one-ulp flips)
+
+    # through autograd: final conv with lazy_dx on the output of a norm + act node
+    cfg = Fn.NormCfg("instance", c, slope=0.1, p=drop_p)
+    spec = Fn.ConvSpec("conv", c, k, 1, 1, 0)
+    bias = torch.zeros(k, device=DEV)
+    outs = []
+    for lazy in (False, True):
+        Fn.DropoutState._salt = 0
+        zz = z.clone().requires_grad_(True)
+        gg, bb, ww = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        fin = (ww, bias, False) if lazy else None            # lazy: forward fused as well (Fn.FusedFinal)
+        a = Fn.NormActFn.apply(zz, None, gg, bb, None, cfg, True, None, None, False, None, False, 1, None, None, fin)
+        y, _ = Fn.ConvFn.apply(a, None, ww, bias, spec, False, False, 0, False, lazy)
+        y.backward(gz)
+        torch.cuda.synchronize()
+        outs.append((zz.grad.float(), gg.grad, bb.grad, ww.grad, y.detach().float()))
+    assert not Fn.LazyDx._by_ptr and not Fn.FusedFinal._by_ptr
+    dy = (outs[0][4] - outs[1][4]).abs()
+    assert bool((dy <= 2.0 ** -7 * outs[0][4].abs() + 1e-6).all()), float(dy.max())
+    assert float((outs[0][0] - outs[1][0]).abs().max()) <= 2 * bound
+    for j in (1, 2, 3):
+        close_f32_sum(outs[1][j].cpu(), outs[0][j].cpu(), f"grad {j}")

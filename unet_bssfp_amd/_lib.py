@@ -57,7 +57,9 @@ class NormActDesc(C.Structure):
                 ("da", _vp), ("ldda", _i32), ("dz", _vp), ("lddz", _i32),
                 ("part", _vp), ("blocks_per_group", _i32), ("sums", _vp), ("batch_stats", _i32),
                 ("s2d_a", _i32), ("s2d_da", _i32), ("sd", _i32), ("sh", _i32), ("sw", _i32), ("seed_ptr", _vp),
-                ("n_affine", _i32), ("q8", _vp), ("ld8", _i32), ("q_use", _vp), ("q_next", _vp)]
+                ("n_affine", _i32), ("q8", _vp), ("ld8", _i32), ("q_use", _vp), ("q_next", _vp),
+                ("gz", _vp), ("ldgz", _i32), ("gw", _vp), ("gw_ld", _i32), ("gk", _i32),
+                ("fy", _vp), ("ldfy", _i32), ("fcp", _i32), ("fbias", _vp), ("skip_a", _i32)]
 
 
 class NormSmallDesc(C.Structure):

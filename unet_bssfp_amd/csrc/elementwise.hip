@@ -450,6 +450,12 @@ struct NormActArgs {
   S2D s2d_a;      // forward: write `a` in space-to-depth layout
   S2D s2d_da;     // backward: read `da` from a space-to-depth tensor
   uint8_t* q8; int ld8; const float* q_use; float* q_next;   // e4m3 copy of a (fwd) / dz (bwd_apply), bf16 with c == 32 only
+  // backward, optional: da is NOT materialised -- it is the data gradient of the 1x1x1 convolution that consumed a:
+  // da[row][ch] = bf16(sum_k gz[row][k] * gw[k][ch]), k < gk <= 8 (bf16 only)
+  const char* gz; int ldgz; const float* gw; int gw_ld; int gk;
+  // forward, optional: the 1x1x1 convolution that consumes a, evaluated per row on the rounded bf16 values:
+  // fy[row][k] = bf16(sum_ch a[row][ch] * bf16(gw[k][ch]) + fbias[k]), k < gk <= 8, channels gk .. fcp - 1 zero; skip_a: a itself is not stored
+  char* fy; int ldfy; int fcp; const float* fbias; int skip_a;
 };
 
 template <typename T, bool DROP>
@@ -504,6 +510,103 @@ __global__ __launch_bounds__(256) void normact_fwd_kernel(const NormActArgs q) {
   }
 }
 
+// Norm + act of a 32-channel bf16 tensor TOGETHER WITH the 1x1x1 convolution that consumes it (NormActArgs::fy: the U-Net's last block
+// and its final convolution), the convolution on the MATRIX pipe.  (A first form kept the thread = 8 channels mapping of the kernel above
+// and used v_dot2c_f32_bf16 with the weights in LDS: 32 dot products, 8 LDS reads and 16 cross-lane adds per thread and row -- 98 us for
+// a 128^3 tensor against 57 us for the plain kernel + 57 us for the convolution launch it replaces.)  Here a wave owns 32 consecutive rows, lane (r, h) holds channels 16 h .. 16 h + 15
+// of row r (two 16-byte pieces: 32 contiguous bytes), and the rounded bf16 words it stores ARE the B operand of two
+// v_mfma_f32_32x32x16_bf16 (k-slot (h, e) of MFMA t = channel 16 h + 8 t + e; A = the weights, rows = outputs, only 8 of 32 used):
+// lane (r, h) ends up with outputs 4 h .. 4 h + 3 of row r -- one 8-byte store.
+template <bool DROP>
+__global__ __launch_bounds__(256) void normact_fwd_final32_kernel(const NormActArgs q) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int g = blockIdx.y;
+  const unsigned long long seed = DROP ? eff_seed(q.seed, q.seed_ptr) : 0ull;
+  float sc[16], sh[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int ch = 16 * h + j;
+    const float ga = q.gamma ? (ch < q.n_affine ? q.gamma[ch] : 0.f) : 1.f, be = (q.beta && ch < q.n_affine) ? q.beta[ch] : 0.f;
+    if (q.mean) {
+      const float rs = q.rstd[(long long)g * 32 + ch], mu = q.mean[(long long)g * 32 + ch];
+      sc[j] = ga * rs;
+      sh[j] = be - mu * ga * rs;
+    } else { sc[j] = ga; sh[j] = be; }
+  }
+  // A fragments: row m = r (an output channel, < gk), k-slot (h, e) of MFMA t = input channel 16 h + 8 t + e
+  uint4 wf[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = 16 * h + 8 * t + 2 * i;
+      const float lo = (r < q.gk && ch < q.gw_ld) ? q.gw[(long long)r * q.gw_ld + ch] : 0.f;
+      const float hi = (r < q.gk && ch + 1 < q.gw_ld) ? q.gw[(long long)r * q.gw_ld + ch + 1] : 0.f;
+      w[i] = (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+    }
+    wf[t] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  float fb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) fb[j] = (q.fbias && 4 * h + j < q.gk) ? q.fbias[4 * h + j] : 0.f;
+  const bf16_t* zb = reinterpret_cast<const bf16_t*>(q.z) + (long long)g * q.rows_per_group * q.ldz;
+  bf16_t* ab = reinterpret_cast<bf16_t*>(q.a) + (long long)g * q.rows_per_group * q.lda;
+  bf16_t* yb = reinterpret_cast<bf16_t*>(q.fy) + (long long)g * q.rows_per_group * q.ldfy;
+  const long long stride = (long long)gridDim.x * 128;
+  // (the next block's rows are loaded before this block's are processed: load -> math -> MFMA -> store is one dependent chain per
+  //  wave, and four waves per SIMD do not cover a memory latency with it)
+  const long long first = (long long)blockIdx.x * 128 + wave * 32;
+  uint4 zn[2];
+  if (first < q.rows_per_group) {
+    const long long rc = first + r < q.rows_per_group ? first + r : q.rows_per_group - 1;
+    zn[0] = *reinterpret_cast<const uint4*>(zb + rc * q.ldz + 16 * h);
+    zn[1] = *reinterpret_cast<const uint4*>(zb + rc * q.ldz + 16 * h + 8);
+  }
+  for (long long row0 = first; row0 < q.rows_per_group; row0 += stride) {      // wave-uniform
+    const long long row = row0 + r;
+    const bool ok = row < q.rows_per_group;
+    const long long rowc = ok ? row : q.rows_per_group - 1;
+    const uint4 zc[2] = {zn[0], zn[1]};
+    if (row0 + stride < q.rows_per_group) {
+      const long long rc = row + stride < q.rows_per_group ? row + stride : q.rows_per_group - 1;
+      zn[0] = *reinterpret_cast<const uint4*>(zb + rc * q.ldz + 16 * h);
+      zn[1] = *reinterpret_cast<const uint4*>(zb + rc * q.ldz + 16 * h + 8);
+    }
+    uint4 aw[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      Vec16<bf16_t> v;
+      v.from_bits(zc[t]);
+      unsigned keep = 0;
+      if constexpr (DROP) keep = drop_keep_mask<8>(seed, ((unsigned long long)g * q.rows_per_group + rowc) * 32 + 16 * h + 8 * t, q.thr16);
+      unsigned w[4];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float x = v.f[j] * sc[8 * t + j] + sh[8 * t + j];
+        if constexpr (DROP) x = (keep >> j) & 1u ? x * q.drop_scale : 0.f;
+        v.f[j] = x > 0.f ? x : x * q.slope;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w[i] = (unsigned)f32_to_bf16_bits(v.f[2 * i]) | ((unsigned)f32_to_bf16_bits(v.f[2 * i + 1]) << 16);
+      aw[t] = make_uint4(w[0], w[1], w[2], w[3]);
+      if (ok && !q.skip_a) *reinterpret_cast<uint4*>(ab + row * q.lda + 16 * h + 8 * t) = aw[t];
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[0]), __builtin_bit_cast(bf16x8, aw[0]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[1]), __builtin_bit_cast(bf16x8, aw[1]), acc, 0, 0, 0);
+    if (ok) {
+      // outputs 4 h .. 4 h + 3 of this lane's row (accumulator registers 0..3), then the zero padding of channels 8 .. fcp - 1
+      const uint2 yv = make_uint2((uint32_t)f32_to_bf16_bits(acc[0] + fb[0]) | ((uint32_t)f32_to_bf16_bits(acc[1] + fb[1]) << 16),
+                                  (uint32_t)f32_to_bf16_bits(acc[2] + fb[2]) | ((uint32_t)f32_to_bf16_bits(acc[3] + fb[3]) << 16));
+      *reinterpret_cast<uint2*>(yb + row * q.ldfy + 4 * h) = yv;
+      for (int c0 = 8 + 4 * h; c0 < q.fcp; c0 += 8) *reinterpret_cast<uint2*>(yb + row * q.ldfy + c0) = make_uint2(0u, 0u);
+    }
+  }
+}
+
 // per-thread channel constants of the backward kernels
 template <int EPV> struct BwdConst { float mu[EPV], rs[EPV], ga[EPV], be[EPV]; };
 template <int EPV>
@@ -515,6 +618,43 @@ __device__ __forceinline__ void load_bwd_const(const NormActArgs& q, int g, int 
     k.rs[j] = q.mean ? q.rstd[(long long)g * q.c + ch] : 1.f;
     k.ga[j] = q.gamma ? (ch < q.n_affine ? q.gamma[ch] : 0.f) : 1.f;
     k.be[j] = (q.beta && ch < q.n_affine) ? q.beta[ch] : 0.f;
+  }
+}
+// implicit da (NormActArgs::gz): the 1x1x1 weights as bf16 PAIRS (k even | k odd), one uint4 per channel in LDS (512 B for 32
+// channels: as registers -- 64 f32 or 32 packed -- they took the streaming kernels from 5 waves per SIMD to 3-4 and made them
+// slower than reading the materialised gradient), and one row's EPV gradients by v_dot2c_f32_bf16 on the row's raw bf16 pairs.
+// The weights are rounded to bf16 like the packed weights of the launch this replaces.
+constexpr int kImplicitMaxC = 64;
+__device__ __forceinline__ void fill_implicit_w(const NormActArgs& q, uint4* wtab) {
+  const int ch = threadIdx.x;
+  if (ch < q.c && ch < kImplicitMaxC) {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool okc = ch < q.gw_ld;
+      const float lo = (okc && 2 * i < q.gk) ? q.gw[(long long)(2 * i) * q.gw_ld + ch] : 0.f;
+      const float hi = (okc && 2 * i + 1 < q.gk) ? q.gw[(long long)(2 * i + 1) * q.gw_ld + ch] : 0.f;
+      w[i] = (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+    }
+    wtab[ch] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  __syncthreads();
+}
+template <typename T, int EPV>
+__device__ __forceinline__ void implicit_da(const NormActArgs& q, long long grow, const uint4* wtab, int ch0, Vec16<T>& dv) {
+  if constexpr (sizeof(T) == 2) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const uint4 gv = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(q.gz) + grow * q.ldgz);   // channels 0..7 (gk <= 8)
+    asm volatile("" : "+v"(ch0));      // opaque per row: otherwise the table reads are hoisted out of the row loop into 32 registers
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+      const uint4 wv = wtab[ch0 + j];
+      float t = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, gv.x), __builtin_bit_cast(bf16x2, wv.x), 0.f, false);
+      t = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, gv.y), __builtin_bit_cast(bf16x2, wv.y), t, false);
+      t = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, gv.z), __builtin_bit_cast(bf16x2, wv.z), t, false);
+      t = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, gv.w), __builtin_bit_cast(bf16x2, wv.w), t, false);
+      dv.f[j] = bf16_bits_to_f32(f32_to_bf16_bits(t));                   // what a stored bf16 gradient would hold
+    }
   }
 }
 // g = da * dropout * lrelu'(pre);  xhat = (z - mean) * rstd  (xhat = z when there is no norm)
@@ -531,7 +671,7 @@ __device__ __forceinline__ void bwd_elem(const NormActArgs& q, bool keep, float 
   gout = pre > 0.f ? gv : gv * q.slope;
 }
 
-template <typename T, bool DROP>
+template <typename T, bool DROP, bool IMPL = false>
 __global__ __launch_bounds__(256) void normact_bwd_reduce_kernel(const NormActArgs q) {
   constexpr int EPV = Elem<T>::kPer16B;
   const int g = blockIdx.y, b = blockIdx.x;
@@ -545,11 +685,14 @@ __global__ __launch_bounds__(256) void normact_bwd_reduce_kernel(const NormActAr
   BwdConst<EPV> k;
   load_bwd_const<EPV>(q, g, (int)(threadIdx.x % (q.c / EPV)) * EPV, k);
   const unsigned long long seed = DROP ? eff_seed(q.seed, q.seed_ptr) : 0ull;
+  __shared__ uint4 wtab[IMPL ? kImplicitMaxC : 1];
+  if constexpr (IMPL) fill_implicit_w(q, wtab);
   block_channel_sums<T>(q.c, r0, r1,
       [&](long long row, int ch0, float* s0, float* s1) {
         Vec16<T> zv, dv;
         zv.load(zb + row * q.ldz + ch0);
-        if (q.s2d_da.d) dv.load(reinterpret_cast<const T*>(q.da) + s2d_offset(q.s2d_da, (long long)g * q.rows_per_group + row, q.ldda) + ch0);
+        if constexpr (IMPL) implicit_da<T, EPV>(q, (long long)g * q.rows_per_group + row, wtab, ch0, dv);
+        else if (q.s2d_da.d) dv.load(reinterpret_cast<const T*>(q.da) + s2d_offset(q.s2d_da, (long long)g * q.rows_per_group + row, q.ldda) + ch0);
         else dv.load(db + row * q.ldda + ch0);
         unsigned keep = 0;
         if constexpr (DROP) keep = drop_keep_mask<EPV>(seed, ((unsigned long long)g * q.rows_per_group + row) * q.c + ch0, q.thr16);
@@ -587,9 +730,11 @@ __global__ __launch_bounds__(1024) void normact_bwd_finalize_kernel(const float*
   }
 }
 
-template <typename T, bool DROP>
-__global__ __launch_bounds__(256) void normact_bwd_apply_kernel(const NormActArgs q) {
+template <typename T, bool DROP, bool IMPL = false>
+__global__ __launch_bounds__(256, IMPL ? 5 : 1) void normact_bwd_apply_kernel(const NormActArgs q) {   // (IMPL: 97 registers without the bound: 4 waves)
   constexpr int EPV = Elem<T>::kPer16B;
+  __shared__ uint4 wtab[IMPL ? kImplicitMaxC : 1];
+  if constexpr (IMPL) fill_implicit_w(q, wtab);          // (before the early return below: it ends with a barrier)
   const int g = blockIdx.y;
   const int lpr = q.c / EPV, rpp = 256 / lpr;
   const int piece = threadIdx.x % lpr, rsub = threadIdx.x / lpr;
@@ -617,7 +762,8 @@ __global__ __launch_bounds__(256) void normact_bwd_apply_kernel(const NormActArg
   for (long long row = (long long)blockIdx.x * rpp + rsub; row < q.rows_per_group; row += stride) {
     Vec16<T> zv, dv;
     zv.load(zb + row * q.ldz + ch0);
-    if (q.s2d_da.d) dv.load(reinterpret_cast<const T*>(q.da) + s2d_offset(q.s2d_da, (long long)g * q.rows_per_group + row, q.ldda) + ch0);
+    if constexpr (IMPL) implicit_da<T, EPV>(q, (long long)g * q.rows_per_group + row, wtab, ch0, dv);
+    else if (q.s2d_da.d) dv.load(reinterpret_cast<const T*>(q.da) + s2d_offset(q.s2d_da, (long long)g * q.rows_per_group + row, q.ldda) + ch0);
     else dv.load(db + row * q.ldda + ch0);
     unsigned keep = 0;
     if constexpr (DROP) keep = drop_keep_mask<EPV>(seed, ((unsigned long long)g * q.rows_per_group + row) * q.c + ch0, q.thr16);
@@ -1552,6 +1698,16 @@ static int fill_normact(const mi355_normact_desc* d, NormActArgs* q, const char*
                            !d->s2d_a && !d->s2d_da),
                 "%s: the e4m3 copy is written for plain bf16 tensors of 32 channels (q8, q_use, q_next)", who);
   q->q8 = (uint8_t*)d->q8; q->ld8 = d->ld8; q->q_use = d->q_use; q->q_next = d->q_next;
+  MI355_REQUIRE(!d->gz || (d->dtype == MI355_DT_BF16 && !d->da && !d->s2d_da && d->gw && d->gk > 0 && d->gk <= 8 && d->ldgz >= 8 &&
+                           d->ldgz % 8 == 0 && d->gw_ld > 0 && d->c <= kImplicitMaxC),
+                "%s: the implicit 1x1x1 data gradient needs bf16, gz rows of >= 8 channels, gk <= 8 and no da", who);
+  q->gz = (const char*)d->gz; q->ldgz = d->ldgz; q->gw = d->gw; q->gw_ld = d->gw_ld; q->gk = d->gk;
+  MI355_REQUIRE(!d->fy || (d->dtype == MI355_DT_BF16 && d->gw && d->gk > 0 && d->gk <= 8 && d->gw_ld > 0 && d->c == 32 &&
+                           d->fcp >= 8 && d->fcp % 8 == 0 && d->fcp <= d->c && d->ldfy >= d->fcp && d->ldfy % 8 == 0 && !d->s2d_a &&
+                           !d->q8 && d->ldz % 8 == 0 && (d->skip_a || d->lda % 8 == 0)),
+                "%s: the fused 1x1x1 convolution needs bf16, 32 channels, gk <= 8 outputs in rows of fcp (8 .. 32) channels", who);
+  MI355_REQUIRE(!d->skip_a || d->fy, "%s: skip_a without the fused convolution", who);
+  q->fy = (char*)d->fy; q->ldfy = d->ldfy; q->fcp = d->fcp; q->fbias = d->fbias; q->skip_a = d->skip_a;
   if (d->s2d_a || d->s2d_da) {
     MI355_REQUIRE((long long)d->sd * d->sh * d->sw * (d->groups == 1 ? 1 : 1) > 0 &&
                   ((long long)d->rows_per_group * d->groups) % ((long long)d->sd * d->sh * d->sw) == 0,
@@ -1577,11 +1733,17 @@ int mi355_normact_fwd(const mi355_normact_desc* d, void* stream) {
   NormActArgs q;
   int rc = fill_normact(d, &q, "normact_fwd");
   if (rc) return rc;
-  MI355_REQUIRE(d->a && d->lda >= d->c, "normact_fwd: bad output");
+  MI355_REQUIRE((d->a && d->lda >= d->c) || d->skip_a, "normact_fwd: bad output");
   dim3 grid(stream_blocks(d->rows_per_group, d->c, d->dtype), d->groups);
   if (d->dtype == MI355_DT_F32) {
     if (q.thr16) normact_fwd_kernel<float, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
     else normact_fwd_kernel<float, false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+  } else if (q.fy) {
+    // (32 channels: the convolution on the matrix pipe; 128 rows per workgroup and pass)
+    long long b = (d->rows_per_group + 128 * 16 - 1) / (128 * 16);
+    const dim3 grid32((unsigned)(b < 1 ? 1 : (b > 1024 ? 1024 : b)), d->groups);
+    if (q.thr16) normact_fwd_final32_kernel<true><<<grid32, dim3(256), 0, (hipStream_t)stream>>>(q);
+    else normact_fwd_final32_kernel<false><<<grid32, dim3(256), 0, (hipStream_t)stream>>>(q);
   } else {
     if (q.thr16) normact_fwd_kernel<bf16_t, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
     else normact_fwd_kernel<bf16_t, false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
@@ -1593,11 +1755,14 @@ int mi355_normact_bwd_reduce(const mi355_normact_desc* d, void* stream) {
   NormActArgs q;
   int rc = fill_normact(d, &q, "normact_bwd_reduce");
   if (rc) return rc;
-  MI355_REQUIRE(d->da && d->part && d->blocks_per_group > 0 && d->ldda >= d->c, "normact_bwd_reduce: bad argument");
+  MI355_REQUIRE((d->gz || (d->da && d->ldda >= d->c)) && d->part && d->blocks_per_group > 0, "normact_bwd_reduce: bad argument");
   dim3 grid(d->blocks_per_group, d->groups);
   if (d->dtype == MI355_DT_F32) {
     if (q.thr16) normact_bwd_reduce_kernel<float, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
     else normact_bwd_reduce_kernel<float, false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+  } else if (q.gz) {
+    if (q.thr16) normact_bwd_reduce_kernel<bf16_t, true, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+    else normact_bwd_reduce_kernel<bf16_t, false, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
   } else {
     if (q.thr16) normact_bwd_reduce_kernel<bf16_t, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
     else normact_bwd_reduce_kernel<bf16_t, false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
@@ -1623,12 +1788,15 @@ int mi355_normact_bwd_apply(const mi355_normact_desc* d, void* stream) {
   NormActArgs q;
   int rc = fill_normact(d, &q, "normact_bwd_apply");
   if (rc) return rc;
-  MI355_REQUIRE(d->da && d->dz && d->ldda >= d->c && d->lddz >= d->c, "normact_bwd_apply: bad argument");
+  MI355_REQUIRE((d->gz || (d->da && d->ldda >= d->c)) && d->dz && d->lddz >= d->c, "normact_bwd_apply: bad argument");
   MI355_REQUIRE(!(d->mean && d->batch_stats) || d->sums, "normact_bwd_apply: sums required");
   dim3 grid(stream_blocks(d->rows_per_group, d->c, d->dtype), d->groups);
   if (d->dtype == MI355_DT_F32) {
     if (q.thr16) normact_bwd_apply_kernel<float, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
     else normact_bwd_apply_kernel<float, false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+  } else if (q.gz) {
+    if (q.thr16) normact_bwd_apply_kernel<bf16_t, true, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+    else normact_bwd_apply_kernel<bf16_t, false, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
   } else {
     if (q.thr16) normact_bwd_apply_kernel<bf16_t, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
     else normact_bwd_apply_kernel<bf16_t, false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);

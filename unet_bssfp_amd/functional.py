@@ -290,6 +290,59 @@ class ColSumSide:
         cls._by_ptr.clear()
 
 
+class LazyDx:
+    """A data gradient that is never materialised: the 1x1x1 final convolution of the U-Net hands (dz, W) to the norm + act
+    node that produced its input, whose backward kernels form da = dz @ W per row on the fly (ops.normact_bwd, implicit=)
+    instead of reading a 134-MB tensor twice that a separate launch would have written.  The convolution's backward returns an
+    UNINITIALISED placeholder of da's shape (allocation only) and registers the operands under it; only a node that was
+    promised as the single consumer at forward time (ConvFn lazy_dx=True, set by BasicUNet) may receive it."""
+    _by_ptr = {}
+    enabled = True
+
+    @classmethod
+    def put(cls, placeholder: torch.Tensor, gz: torch.Tensor, gw: torch.Tensor):
+        if len(cls._by_ptr) >= 8:
+            cls._by_ptr.clear()
+        cls._by_ptr[placeholder.data_ptr()] = (gz, gw, tuple(placeholder.shape), placeholder)
+
+    @classmethod
+    def take(cls, t: torch.Tensor):
+        hit = cls._by_ptr.pop(t.data_ptr(), None)
+        return (hit[0], hit[1]) if hit is not None and hit[2] == tuple(t.shape) else None
+
+    @classmethod
+    def clear(cls):
+        cls._by_ptr.clear()
+
+
+class FusedFinal:
+    """Output of a 1x1x1 convolution that the norm + act launch producing its input has already computed (ops.normact_fwd,
+    final=): NormActFn.forward registers it under the activation, ConvFn.forward (lazy_dx=True: same single-consumer promise as
+    LazyDx) takes it instead of launching.  The convolution stays an autograd node: its weight / bias gradients and the LazyDx
+    hand-over are unchanged."""
+    _by_ptr = {}
+
+    @classmethod
+    def put(cls, a: torch.Tensor, y: torch.Tensor, w: torch.Tensor):
+        if len(cls._by_ptr) >= 8:
+            cls._by_ptr.clear()
+        cls._by_ptr[a.data_ptr()] = (y, w, w._version, tuple(a.shape), a)
+
+    @classmethod
+    def take(cls, a: torch.Tensor, w: torch.Tensor):
+        hit = cls._by_ptr.pop(a.data_ptr(), None)
+        if hit is None:
+            return None
+        if hit[3] != tuple(a.shape) or hit[1].data_ptr() != w.data_ptr() or hit[2] != w._version:
+            # (the activation may not even have been written: never fall back to a launch that would read it)
+            raise RuntimeError("FusedFinal: the convolution that takes the precomputed output is not the one it was computed for")
+        return hit[0]
+
+    @classmethod
+    def clear(cls):
+        cls._by_ptr.clear()
+
+
 def fp8_operand(x: torch.Tensor, slot: "Fp8Scales.Slot", constant: bool = False) -> torch.Tensor:
     """The e4m3 copy of a convolution operand with the amax in ``slot.use``: the one its producer wrote if there is one;
     otherwise one cast pass with the previous step's amax (gathering this step's); on the slot's first step the in-step
@@ -571,7 +624,9 @@ class ConvFn(Function):
 
     @staticmethod
     def forward(ctx, x0, x1, weight, bias, spec: ConvSpec, want_stats: bool, zero_bias_grad: bool = False,
-                s2d_cp: int = 0, fp8: bool = False):
+                s2d_cp: int = 0, fp8: bool = False, lazy_dx: bool = False):
+        # lazy_dx: the caller guarantees that x0 is the output of a (non-small, plain-layout) NormActFn node and has no other
+        # consumer: a 1x1x1 convolution then leaves its data gradient to that node's backward kernels (LazyDx)
         x0 = ops.as_act(x0)
         x1 = ops.as_act(x1) if x1 is not None else None
         n, di, hi, wi, c0 = x0.shape
@@ -610,6 +665,8 @@ class ConvFn(Function):
                 part = torch.empty((tiles, 2, coutp), dtype=torch.float32, device=dev)
             ops.conv_fwd(x8, None, wp, coutp, bp, 3, 1, (1, 1, 1), out, (do_, ho, wo), stats=part,
                          real=(spec.cin, spec.cout), fp8=q)
+        elif lazy_dx and spec.kind == "conv" and spec.ks == 1 and (pre := FusedFinal.take(x0, weight)) is not None:
+            out = pre                          # computed by the launch that produced x0 (ops.normact_fwd, final=)
         elif spec.kind == "conv":
             wp, coutp, _ = spec.w_fwd(weight, dtype, c0 + c1)
             bp = bias.detach() if bias is not None else None
@@ -635,6 +692,8 @@ class ConvFn(Function):
         ctx.save_for_backward(x0, x1, weight)
         ctx.spec = spec
         ctx.fp8 = fp8
+        ctx.lazy_dx = bool(lazy_dx and LazyDx.enabled and spec.kind == "conv" and spec.ks == 1 and spec.stride == 1 and x1 is None
+                           and not s2d_cp and dtype == torch.bfloat16 and spec.cout <= 8 and spec.cin <= c0)
         ctx.has_bias = bias is not None
         ctx.bias_param, ctx.weight_param = bias, weight    # (their .grad may live in a GradBuckets buffer: gradsink.py)
         # a normalisation with batch/instance statistics follows: the mean subtraction cancels the bias,
@@ -650,7 +709,7 @@ class ConvFn(Function):
     @once_differentiable
     def backward(ctx, dz, _dpart):
         if dz is None:                        # the conv output did not reach the loss
-            return (None,) * 9
+            return (None,) * 10
         x0, x1, weight = ctx.saved_tensors
         spec: ConvSpec = ctx.spec
         dz = ops.as_act(dz)
@@ -663,7 +722,10 @@ class ConvFn(Function):
         k = spec.ks
         dx0 = dx1 = dw = db = None
         need_dx = ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1])
-        if need_dx:
+        if need_dx and ctx.lazy_dx:
+            dx0 = ops.new_act(n, di, hi, wi, c0, dtype, dev)       # placeholder: never written, never read (LazyDx)
+            LazyDx.put(dx0, dz, ctx.weight_param.detach())
+        elif need_dx:
             dxc = ops.new_act(n, di, hi, wi, c0 + c1, dtype, dev)
             # the second source of a skip concatenation comes from a transposed convolution whose bias gradient is the
             # per-channel sum of this data gradient: let the launch that writes it emit the sums (fused statistics)
@@ -761,7 +823,7 @@ class ConvFn(Function):
                 ops.colsum_from_parts(carried[0], carried[1], db)
             else:
                 db = ops.colsum(dz)[: spec.cout].contiguous()
-        return dx0, dx1, dw, db, None, None, None, None, None
+        return dx0, dx1, dw, db, None, None, None, None, None, None
 
 
 class StepMemo:
@@ -1052,6 +1114,8 @@ class DropoutState:
         PackMemo.clear()                    # a new training step: constant inputs are packed afresh
         StepMemo.clear()
         ColSumSide.clear()
+        LazyDx.clear()
+        FusedFinal.clear()
         Fp8Scales.advance(device)           # ... and the e4m3 scales gathered in the last step come into use
 
     @classmethod
@@ -1066,7 +1130,7 @@ class NormActFn(Function):
     @staticmethod
     def forward(ctx, z, part, gamma, beta, conv_bias, cfg: NormCfg, training, running_mean, running_var,
                 s2d_out: bool = False, batches_tracked=None, small: bool = False, bn_groups: int = 1,
-                emit8=None, emit8_bwd=None):
+                emit8=None, emit8_bwd=None, final=None):
         """bn_groups > 1: BatchNorm statistics per consecutive sample group (two forward calls of the discriminator stacked
         along the batch: each group is normalised with its own batch statistics, the running statistics receive the groups'
         momentum updates in order -- exactly what two separate calls do)."""
@@ -1142,6 +1206,14 @@ class NormActFn(Function):
             a = ops.normact_fwd(z, groups, mean, rstd, gp, bp, cfg.slope, p, seed, seed_t=seed_t, q8=(a8, emit8.use, emit8.next))
             emit8.touched = True
             Fp8Side.put(a, a8)
+        elif final is not None and z.dtype == torch.bfloat16 and c == 32:
+            # final = (weight, bias, skip_a) of the 1x1x1 convolution that is this node's ONLY consumer (BasicUNet.final_conv):
+            # computed in the same pass; without autograd (skip_a) the activation itself is not even written
+            fw, fb, skip_a = final               # (skip_a is the CALLER's `not torch.is_grad_enabled()`: in here grad mode is always off)
+            y = ops.new_act(n, d, h, w, round_up(fw.shape[0], 16), z.dtype, z.device)
+            a = ops.normact_fwd(z, groups, mean, rstd, gp, bp, cfg.slope, p, seed, seed_t=seed_t,
+                                final=(fw.detach(), fb.detach() if fb is not None else None, y), skip_a=skip_a)
+            FusedFinal.put(a, y, fw)
         else:
             a = ops.normact_fwd(z, groups, mean, rstd, gp, bp, cfg.slope, p, seed, seed_t=seed_t)
         ctx.s2d_out = s2d_out
@@ -1157,6 +1229,11 @@ class NormActFn(Function):
         z, mean, rstd, gp, bp = ctx.saved_tensors
         groups, slope, p, seed, batch_stats, nch = ctx.meta
         da = ops.as_act(da)
+        lazy = LazyDx.take(da)                  # (dz, W) of the 1x1x1 convolution that consumed a: da is formed on the fly
+        if lazy is not None:
+            if ctx.small or ctx.s2d_out:
+                raise RuntimeError("LazyDx placeholder reached a norm node that cannot form the gradient itself")
+            da = None
         want_affine = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
         gamma_p, beta_p = ctx.affine_params
         sink = sink_of(gamma_p) if (ctx.needs_input_grad[2] and ctx.needs_input_grad[3] and mean is not None) else None
@@ -1169,7 +1246,7 @@ class NormActFn(Function):
                 Fp8Side.put(dz, q8[0])
             return dz
         if ctx.small:
-            none11 = (None,) * 14
+            none11 = (None,) * 15
             if sink is not None and sink_of(beta_p) is sink:
                 dz, _, _ = ops.normact_small_bwd(z, da, groups, mean, rstd, gp, bp, slope, p, seed, batch_stats, s2d=ctx.s2d_out,
                                                  seed_t=ctx.seed_t, affine_into=(sink_grad(gamma_p), sink_grad(beta_p)),
@@ -1181,20 +1258,21 @@ class NormActFn(Function):
                                                       s2d=ctx.s2d_out, seed_t=ctx.seed_t, want_affine=want_affine)
             dg = dgamma[:nch].contiguous() if (dgamma is not None and ctx.needs_input_grad[2]) else None
             dbt = dbeta[:nch].contiguous() if (dbeta is not None and ctx.needs_input_grad[3]) else None
-            return (dz, None, dg, dbt) + (None,) * 11
+            return (dz, None, dg, dbt) + (None,) * 12
         if sink is not None and sink_of(beta_p) is sink:
             # both affine gradients straight into the parameters' .grad storage (gradsink.py)
             dz, _, _ = ops.normact_bwd(z, da, groups, mean, rstd, gp, bp, slope, p, seed, batch_stats, True,
                                        s2d=ctx.s2d_out, seed_t=ctx.seed_t, affine_into=(sink_grad(gamma_p), sink_grad(beta_p)),
-                                       accumulate=not sink.fresh(gamma_p), q8=q8)
+                                       accumulate=not sink.fresh(gamma_p), q8=q8, implicit=lazy)
             sink.written(gamma_p)
             sink.written(beta_p)
-            return (done(dz),) + (None,) * 14
+            return (done(dz),) + (None,) * 15
         dz, dgamma, dbeta = ops.normact_bwd(z, da, groups, mean, rstd, gp, bp, slope, p, seed, batch_stats,
-                                            want_affine and mean is not None, s2d=ctx.s2d_out, seed_t=ctx.seed_t, q8=q8)
+                                            want_affine and mean is not None, s2d=ctx.s2d_out, seed_t=ctx.seed_t, q8=q8,
+                                            implicit=lazy)
         dg = dgamma[:nch].contiguous() if (dgamma is not None and ctx.needs_input_grad[2]) else None
         dbt = dbeta[:nch].contiguous() if (dbeta is not None and ctx.needs_input_grad[3]) else None
-        return (done(dz), None, dg, dbt) + (None,) * 11
+        return (done(dz), None, dg, dbt) + (None,) * 12
 
 
 # ====================================================================================== pool / loss

@@ -125,8 +125,8 @@ class Conv3d(_Mi355Module):
             bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
             nn.init.uniform_(self.bias, -bound, bound)
 
-    def forward_act(self, x0, x1=None, want_stats=False, zero_bias_grad=False, s2d_cp=0):
-        return Fn.ConvFn.apply(x0, x1, self.weight, self.bias, self.spec, want_stats, zero_bias_grad, s2d_cp, self.fp8)
+    def forward_act(self, x0, x1=None, want_stats=False, zero_bias_grad=False, s2d_cp=0, lazy_dx=False):
+        return Fn.ConvFn.apply(x0, x1, self.weight, self.bias, self.spec, want_stats, zero_bias_grad, s2d_cp, self.fp8, lazy_dx)
 
     def forward(self, x):
         z, _ = self.forward_act(self._to_act(x))
@@ -365,7 +365,7 @@ class Convolution(_Mi355Module):
         self.adn = _ADN(cout)
         self.cfg = Fn.NormCfg("instance", cout, eps=eps, slope=slope, p=float(dropout or 0.0))
 
-    def forward_act(self, x0, x1=None, feeds: Optional[Conv3d] = None, up_from=None):
+    def forward_act(self, x0, x1=None, feeds: Optional[Conv3d] = None, up_from=None, final: Optional[Conv3d] = None):
         """feeds: the convolution that consumes the result (fp8 mode: the norm kernel writes its e4m3 operand as well);
         up_from = (x_low, deconv module, tables): the second source is ConvTranspose3d(x_low), which is NOT materialised
         (Fn.UpCatConvFn: the up-branch as one transposed 4x4x4 convolution of the low-resolution tensor)"""
@@ -390,8 +390,13 @@ class Convolution(_Mi355Module):
             if (self.conv.fp8 and up_from is None and torch.is_grad_enabled() and (x0.requires_grad or (x1 is not None and x1.requires_grad))
                     and ops.conv_fp8_layer_ok(n, d, h, w, cp, cin)):
                 emit8_bwd = self.conv.spec.fp8_slot("g", z.device)
+        fin = None
+        if (final is not None and not small and z.dtype == torch.bfloat16 and cp == 32 and emit8 is None and final.out_channels <= 8
+                and final.in_channels <= cp and Fn.LazyDx.enabled):
+            # `final` is the 1x1x1 convolution that is this block's only consumer: evaluated by the norm + act launch itself
+            fin = (final.weight, final.bias, not torch.is_grad_enabled())
         return Fn.NormActFn.apply(z, part if not small else None, self.adn.N.weight, self.adn.N.bias, shift, self.cfg,
-                                  self.training, None, None, False, None, small, 1, emit8, emit8_bwd)
+                                  self.training, None, None, False, None, small, 1, emit8, emit8_bwd, fin)
 
 
 class TwoConv(_Mi355Module):
@@ -400,8 +405,8 @@ class TwoConv(_Mi355Module):
         self.conv_0 = Convolution(cin, cout, dropout)
         self.conv_1 = Convolution(cout, cout, dropout)
 
-    def forward_act(self, x0, x1=None, up_from=None):
-        return self.conv_1.forward_act(self.conv_0.forward_act(x0, x1, feeds=self.conv_1.conv, up_from=up_from))
+    def forward_act(self, x0, x1=None, up_from=None, final=None):
+        return self.conv_1.forward_act(self.conv_0.forward_act(x0, x1, feeds=self.conv_1.conv, up_from=up_from), final=final)
 
 
 class Down(_Mi355Module):
@@ -442,11 +447,11 @@ class UpCat(_Mi355Module):
                 and x_e.shape[4] + deconv.out_channels == conv.in_channels and deconv.bias is not None
                 and x.shape[3] >= 32 and not ops.norm_is_small(x_e.shape[0], *x_e.shape[1:4], co))
 
-    def forward_act(self, x, x_e):
+    def forward_act(self, x, x_e, final=None):
         if self._fused(x, x_e):
             if not hasattr(self, "upcat_tables"):
                 self.upcat_tables = Fn.UpCatTables()
-            return self.convs.forward_act(x_e, None, up_from=(x, self.upsample.deconv, self.upcat_tables))
+            return self.convs.forward_act(x_e, None, up_from=(x, self.upsample.deconv, self.upcat_tables), final=final)
         x_0 = self.upsample.deconv.forward_act(x)
         if x_0.shape[1:4] != x_e.shape[1:4]:
             # MONAI UpCat (is_pad): a level whose extent is odd loses its last plane in MaxPool3d(2); the up-sampled map is
@@ -458,11 +463,13 @@ class UpCat(_Mi355Module):
                     x_0 = torch.cat([x_0, x_0.narrow(ax, x_0.shape[ax] - 1, 1)], ax)
             if x_0.shape[1:4] != x_e.shape[1:4]:
                 raise ValueError(f"skip {tuple(x_e.shape[1:4])} and up-sampled map {tuple(x_0.shape[1:4])} differ by more than one")
-        return self.convs.forward_act(x_e, x_0)        # virtual cat([x_e, x_0], 1): skip first
+        return self.convs.forward_act(x_e, x_0, final=final)        # virtual cat([x_e, x_0], 1): skip first
 
 
 class BasicUNet(_Mi355Module):
     """BasicUNet(spatial_dims=3, in_channels, out_channels, features, act, norm, bias, dropout, upsample)."""
+
+    lazy_final_dx = True       # bf16: the final 1x1x1 convolution's data gradient is formed inside upcat_1's norm backward (Fn.LazyDx)
 
     def __init__(self, spatial_dims: int = 3, in_channels: int = 1, out_channels: int = 2,
                  features: Sequence[int] = (32, 32, 64, 128, 256, 32),
@@ -558,8 +565,12 @@ class BasicUNet(_Mi355Module):
         u4 = self.upcat_4.forward_act(x4, s3)
         u3 = self.upcat_3.forward_act(u4, s2)
         u2 = self.upcat_2.forward_act(u3, s1)
-        u1 = self.upcat_1.forward_act(u2, s0)
-        z, _ = self.final_conv.forward_act(u1)
+        # u1 is the output of upcat_1's second norm + act node and feeds nothing but the final 1x1x1 convolution: that node's
+        # launches evaluate the convolution (forward: Fn.FusedFinal) and form its data gradient (backward: Fn.LazyDx) themselves
+        # (bf16, <= 8 output channels)
+        lazy = self.lazy_final_dx and u2.dtype == torch.bfloat16
+        u1 = self.upcat_1.forward_act(u2, s0, final=self.final_conv if lazy else None)
+        z, _ = self.final_conv.forward_act(u1, lazy_dx=lazy and not ops.norm_is_small(*u1.shape))
         return z
 
     def forward(self, x, _embedded: bool = False):

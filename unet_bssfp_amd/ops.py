@@ -593,14 +593,32 @@ def _set_q8(d, q8):
     d.q8, d.ld8, d.q_use, d.q_next = t8.data_ptr(), t8.shape[-1], use.data_ptr(), nxt.data_ptr()
 
 
-def normact_fwd(z, groups, mean, rstd, gamma, beta, slope, drop_p=0.0, seed=0, out=None, s2d=False, seed_t=None, q8=None):
+def normact_fwd(z, groups, mean, rstd, gamma, beta, slope, drop_p=0.0, seed=0, out=None, s2d=False, seed_t=None, q8=None,
+                final=None, skip_a=False):
     """s2d=True: `out` is the space-to-depth tensor S(a) (s2d_shape) instead of a plain one; every slot of it is written.
-    q8: also write the e4m3 copy of the result for the fp8 convolution that consumes it (see _set_q8)."""
+    q8: also write the e4m3 copy of the result for the fp8 convolution that consumes it (see _set_q8).
+    final=(w, bias, y): also evaluate the 1x1x1 convolution that consumes a -- y[..., k] = bf16(a @ bf16(w[k]) + bias[k]), w f32
+    (k <= 8, cin[, 1, 1, 1]), y a bf16 NDHWC tensor on the same grid whose channels beyond k are zeroed; skip_a: a itself is not
+    written (the returned tensor is uninitialised)."""
     require_cuda(z, mean, rstd, gamma, beta, out)
     if out is None:
         out = torch.empty(z.shape, dtype=z.dtype, device=z.device)
     d = _normact_desc(z, groups, mean, rstd, gamma, beta, slope, drop_p, seed, seed_t)
     d.a, d.lda = out.data_ptr(), act_ld(out)
+    keep_final = None
+    if final is not None:
+        fw, fb, fy = final
+        require_cuda(fw, fb, fy)
+        assert not s2d and z.dtype == fy.dtype == torch.bfloat16 and fw.dtype == torch.float32 and fw.is_contiguous()
+        fw2 = fw.detach().reshape(fw.shape[0], -1)
+        assert fw2.shape[0] <= 8 and fw2.shape[1] <= z.shape[4] and tuple(fy.shape[:4]) == tuple(z.shape[:4])
+        assert fb is None or (fb.dtype == torch.float32 and fb.numel() == fw2.shape[0])
+        d.gw, d.gw_ld, d.gk = fw2.data_ptr(), fw2.shape[1], fw2.shape[0]
+        d.fy, d.ldfy, d.fcp, d.fbias = fy.data_ptr(), act_ld(fy), fy.shape[4], _ptr(fb.detach() if fb is not None else None)
+        d.skip_a = 1 if skip_a else 0
+        keep_final = (fw2, fb, fy)
+    else:
+        assert not skip_a
     if q8 is not None:
         _set_q8(d, q8)
     if s2d:
@@ -614,17 +632,30 @@ def normact_fwd(z, groups, mean, rstd, gamma, beta, slope, drop_p=0.0, seed=0, o
 
 
 def normact_bwd(z, da, groups, mean, rstd, gamma, beta, slope, drop_p, seed, batch_stats, want_affine_grads,
-                s2d=False, seed_t=None, affine_into=None, accumulate=False, q8=None):
+                s2d=False, seed_t=None, affine_into=None, accumulate=False, q8=None, implicit=None):
     """Returns (dz, dgamma, dbeta).  dgamma/dbeta are f32 [C] (None if there is no norm).
     s2d=True: `da` is a gradient in space-to-depth layout (the forward wrote S(a)).
     affine_into=(dgamma, dbeta): write (accumulate=True: add) the affine gradients into these caller-owned f32
-    vectors of the real channel count instead of returning new ones (then None, None are returned for them)."""
+    vectors of the real channel count instead of returning new ones (then None, None are returned for them).
+    implicit=(gz, gw): `da` is not materialised (pass None): it is the data gradient of the 1x1x1 convolution that consumed a,
+    da = bf16(gz[..., :k] @ gw) with gz the NDHWC gradient of that convolution's output and gw its f32 weights (k, cin[,1,1,1])."""
     require_cuda(z, da)
     lib = _lib.load()
     n, dd, h, w, c = z.shape
     rows = n * dd * h * w
     d = _normact_desc(z, groups, mean, rstd, gamma, beta, slope, drop_p, seed, seed_t)
-    d.da, d.ldda = da.data_ptr(), act_ld(da)
+    keep_implicit = None
+    if implicit is not None:
+        gz, gw = implicit
+        require_cuda(gz, gw)
+        assert da is None and not s2d and z.dtype == torch.bfloat16 and gz.dtype == torch.bfloat16
+        assert tuple(gz.shape[:4]) == tuple(z.shape[:4]) and gw.dtype == torch.float32 and gw.is_contiguous()
+        gw2 = gw.detach().reshape(gw.shape[0], -1)
+        assert gw2.shape[0] <= 8 and gw2.shape[0] <= gz.shape[4] and gw2.shape[1] <= c
+        d.gz, d.ldgz, d.gw, d.gw_ld, d.gk = gz.data_ptr(), act_ld(gz), gw2.data_ptr(), gw2.shape[1], gw2.shape[0]
+        keep_implicit = (gz, gw2)
+    else:
+        d.da, d.ldda = da.data_ptr(), act_ld(da)
     dz = torch.empty(z.shape, dtype=z.dtype, device=z.device)
     d.dz, d.lddz = dz.data_ptr(), act_ld(dz)
     d.batch_stats = 1 if batch_stats else 0
