@@ -511,21 +511,23 @@ __global__ __launch_bounds__(256) void normact_fwd_kernel(const NormActArgs q) {
 }
 
 // Norm + act of a 32-channel bf16 tensor TOGETHER WITH the 1x1x1 convolution that consumes it (NormActArgs::fy: the U-Net's last block
-// and its final convolution), the convolution on the MATRIX pipe.  (A first form kept the thread = 8 channels mapping of the kernel above
-// and used v_dot2c_f32_bf16 with the weights in LDS: 32 dot products, 8 LDS reads and 16 cross-lane adds per thread and row -- 98 us for
-// a 128^3 tensor against 57 us for the plain kernel + 57 us for the convolution launch it replaces.)  Here a wave owns 32 consecutive rows, lane (r, h) holds channels 16 h .. 16 h + 15
-// of row r (two 16-byte pieces: 32 contiguous bytes), and the rounded bf16 words it stores ARE the B operand of two
-// v_mfma_f32_32x32x16_bf16 (k-slot (h, e) of MFMA t = channel 16 h + 8 t + e; A = the weights, rows = outputs, only 8 of 32 used):
-// lane (r, h) ends up with outputs 4 h .. 4 h + 3 of row r -- one 8-byte store.
+// and its final convolution), the convolution on the MATRIX pipe.  Forms tried at 128^3 (plain kernel 57 us + the convolution launch it
+// replaces 57 us): thread = 8 channels with v_dot2c_f32_bf16, weights in LDS, 16 cross-lane adds per row: 98 us; lane = 16 channels of a
+// row + two v_mfma_f32_32x32x16_bf16 per 32 rows (96 registers + 16 accumulators: 4 waves per SIMD): 65 - 73 us.  This one keeps the plain
+// kernel's work per thread: a wave owns 16 consecutive rows, lane (n, p) = row n, channel piece p (8 channels, one 16-byte load), and the
+// rounded bf16 words it stores ARE the B operand of ONE v_mfma_f32_16x16x32_bf16 (k = 8 p + e; A = the weights, rows = outputs): lane
+// (n, p) ends up with outputs 4 p .. 4 p + 3 of row n -- outputs 8..15 are the zero padding of the 16-channel output row, so every lane
+// stores 8 bytes and the row is complete.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 template <bool DROP>
 __global__ __launch_bounds__(256) void normact_fwd_final32_kernel(const NormActArgs q) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-  const int g = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, p = lane >> 4;
+  const int g = blockIdx.y, ch0 = 8 * p;
   const unsigned long long seed = DROP ? eff_seed(q.seed, q.seed_ptr) : 0ull;
-  float sc[16], sh[16];
+  float sc[8], sh[8];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int ch = 16 * h + j;
+  for (int j = 0; j < 8; ++j) {
+    const int ch = ch0 + j;
     const float ga = q.gamma ? (ch < q.n_affine ? q.gamma[ch] : 0.f) : 1.f, be = (q.beta && ch < q.n_affine) ? q.beta[ch] : 0.f;
     if (q.mean) {
       const float rs = q.rstd[(long long)g * 32 + ch], mu = q.mean[(long long)g * 32 + ch];
@@ -533,76 +535,64 @@ __global__ __launch_bounds__(256) void normact_fwd_final32_kernel(const NormActA
       sh[j] = be - mu * ga * rs;
     } else { sc[j] = ga; sh[j] = be; }
   }
-  // A fragments: row m = r (an output channel, < gk), k-slot (h, e) of MFMA t = input channel 16 h + 8 t + e
-  uint4 wf[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
+  // A fragment: row m = n (an output channel, < gk), k = 8 p + e (input channel)
+  uint4 wf;
+  {
     unsigned w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int ch = 16 * h + 8 * t + 2 * i;
-      const float lo = (r < q.gk && ch < q.gw_ld) ? q.gw[(long long)r * q.gw_ld + ch] : 0.f;
-      const float hi = (r < q.gk && ch + 1 < q.gw_ld) ? q.gw[(long long)r * q.gw_ld + ch + 1] : 0.f;
+      const int ch = ch0 + 2 * i;
+      const float lo = (n < q.gk && ch < q.gw_ld) ? q.gw[(long long)n * q.gw_ld + ch] : 0.f;
+      const float hi = (n < q.gk && ch + 1 < q.gw_ld) ? q.gw[(long long)n * q.gw_ld + ch + 1] : 0.f;
       w[i] = (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
     }
-    wf[t] = make_uint4(w[0], w[1], w[2], w[3]);
+    wf = make_uint4(w[0], w[1], w[2], w[3]);
   }
   float fb[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) fb[j] = (q.fbias && 4 * h + j < q.gk) ? q.fbias[4 * h + j] : 0.f;
+  for (int j = 0; j < 4; ++j) fb[j] = (q.fbias && 4 * p + j < q.gk) ? q.fbias[4 * p + j] : 0.f;
   const bf16_t* zb = reinterpret_cast<const bf16_t*>(q.z) + (long long)g * q.rows_per_group * q.ldz;
   bf16_t* ab = reinterpret_cast<bf16_t*>(q.a) + (long long)g * q.rows_per_group * q.lda;
   bf16_t* yb = reinterpret_cast<bf16_t*>(q.fy) + (long long)g * q.rows_per_group * q.ldfy;
-  const long long stride = (long long)gridDim.x * 128;
-  // (the next block's rows are loaded before this block's are processed: load -> math -> MFMA -> store is one dependent chain per
-  //  wave, and four waves per SIMD do not cover a memory latency with it)
-  const long long first = (long long)blockIdx.x * 128 + wave * 32;
-  uint4 zn[2];
+  const long long stride = (long long)gridDim.x * 64;
+  // (the next block's piece is loaded before this block's is processed: load -> math -> MFMA -> store is one dependent chain per wave)
+  const long long first = (long long)blockIdx.x * 64 + wave * 16;
+  uint4 zn = make_uint4(0u, 0u, 0u, 0u);
   if (first < q.rows_per_group) {
-    const long long rc = first + r < q.rows_per_group ? first + r : q.rows_per_group - 1;
-    zn[0] = *reinterpret_cast<const uint4*>(zb + rc * q.ldz + 16 * h);
-    zn[1] = *reinterpret_cast<const uint4*>(zb + rc * q.ldz + 16 * h + 8);
+    const long long rc = first + n < q.rows_per_group ? first + n : q.rows_per_group - 1;
+    zn = *reinterpret_cast<const uint4*>(zb + rc * q.ldz + ch0);
   }
   for (long long row0 = first; row0 < q.rows_per_group; row0 += stride) {      // wave-uniform
-    const long long row = row0 + r;
+    const long long row = row0 + n;
     const bool ok = row < q.rows_per_group;
     const long long rowc = ok ? row : q.rows_per_group - 1;
-    const uint4 zc[2] = {zn[0], zn[1]};
+    const uint4 zc = zn;
     if (row0 + stride < q.rows_per_group) {
       const long long rc = row + stride < q.rows_per_group ? row + stride : q.rows_per_group - 1;
-      zn[0] = *reinterpret_cast<const uint4*>(zb + rc * q.ldz + 16 * h);
-      zn[1] = *reinterpret_cast<const uint4*>(zb + rc * q.ldz + 16 * h + 8);
+      zn = *reinterpret_cast<const uint4*>(zb + rc * q.ldz + ch0);
     }
-    uint4 aw[2];
+    Vec16<bf16_t> v;
+    v.from_bits(zc);
+    unsigned keep = 0;
+    if constexpr (DROP) keep = drop_keep_mask<8>(seed, ((unsigned long long)g * q.rows_per_group + rowc) * 32 + ch0, q.thr16);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      Vec16<bf16_t> v;
-      v.from_bits(zc[t]);
-      unsigned keep = 0;
-      if constexpr (DROP) keep = drop_keep_mask<8>(seed, ((unsigned long long)g * q.rows_per_group + rowc) * 32 + 16 * h + 8 * t, q.thr16);
-      unsigned w[4];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float x = v.f[j] * sc[8 * t + j] + sh[8 * t + j];
-        if constexpr (DROP) x = (keep >> j) & 1u ? x * q.drop_scale : 0.f;
-        v.f[j] = x > 0.f ? x : x * q.slope;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) w[i] = (unsigned)f32_to_bf16_bits(v.f[2 * i]) | ((unsigned)f32_to_bf16_bits(v.f[2 * i + 1]) << 16);
-      aw[t] = make_uint4(w[0], w[1], w[2], w[3]);
-      if (ok && !q.skip_a) *reinterpret_cast<uint4*>(ab + row * q.lda + 16 * h + 8 * t) = aw[t];
+    for (int j = 0; j < 8; ++j) {
+      float x = v.f[j] * sc[j] + sh[j];
+      if constexpr (DROP) x = (keep >> j) & 1u ? x * q.drop_scale : 0.f;
+      v.f[j] = x > 0.f ? x : x * q.slope;
     }
-    f32x16 acc;
+    unsigned w[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[0]), __builtin_bit_cast(bf16x8, aw[0]), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[1]), __builtin_bit_cast(bf16x8, aw[1]), acc, 0, 0, 0);
-    if (ok) {
-      // outputs 4 h .. 4 h + 3 of this lane's row (accumulator registers 0..3), then the zero padding of channels 8 .. fcp - 1
+    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f32_to_bf16_bits(v.f[2 * i]) | ((unsigned)f32_to_bf16_bits(v.f[2 * i + 1]) << 16);
+    const uint4 aw = make_uint4(w[0], w[1], w[2], w[3]);
+    if (ok && !q.skip_a) *reinterpret_cast<uint4*>(ab + row * q.lda + ch0) = aw;
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, aw), acc, 0, 0, 0);
+    if (ok && 4 * p < q.fcp) {
+      // outputs 4 p .. 4 p + 3 of this lane's row (p >= 2: the padding channels, whose weight rows are zero)
       const uint2 yv = make_uint2((uint32_t)f32_to_bf16_bits(acc[0] + fb[0]) | ((uint32_t)f32_to_bf16_bits(acc[1] + fb[1]) << 16),
                                   (uint32_t)f32_to_bf16_bits(acc[2] + fb[2]) | ((uint32_t)f32_to_bf16_bits(acc[3] + fb[3]) << 16));
-      *reinterpret_cast<uint2*>(yb + row * q.ldfy + 4 * h) = yv;
-      for (int c0 = 8 + 4 * h; c0 < q.fcp; c0 += 8) *reinterpret_cast<uint2*>(yb + row * q.ldfy + c0) = make_uint2(0u, 0u);
+      *reinterpret_cast<uint2*>(yb + row * q.ldfy + 4 * p) = yv;
     }
   }
 }
@@ -1739,9 +1729,10 @@ int mi355_normact_fwd(const mi355_normact_desc* d, void* stream) {
     if (q.thr16) normact_fwd_kernel<float, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
     else normact_fwd_kernel<float, false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
   } else if (q.fy) {
-    // (32 channels: the convolution on the matrix pipe; 128 rows per workgroup and pass)
-    long long b = (d->rows_per_group + 128 * 16 - 1) / (128 * 16);
-    const dim3 grid32((unsigned)(b < 1 ? 1 : (b > 1024 ? 1024 : b)), d->groups);
+    // (the convolution on the matrix pipe; 64 rows per workgroup and pass)
+    MI355_REQUIRE(d->fcp == 16, "normact_fwd: the fused convolution writes 16-channel rows");
+    long long b = (d->rows_per_group + 64 * 8 - 1) / (64 * 8);
+    const dim3 grid32((unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b)), d->groups);
     if (q.thr16) normact_fwd_final32_kernel<true><<<grid32, dim3(256), 0, (hipStream_t)stream>>>(q);
     else normact_fwd_final32_kernel<false><<<grid32, dim3(256), 0, (hipStream_t)stream>>>(q);
   } else {
