@@ -86,6 +86,7 @@ def parse():
     ap.add_argument("--master-port", type=int, default=0, help="self-launch (--gpus N without torch.distributed.run): rendezvous port (0 = pick a free one)")
     ap.add_argument("--eager-final-dx", action="store_true", help="developer A/B: the final 1x1x1 convolution writes its data gradient (one launch, 134 MB) instead of leaving it to the norm backward kernels (Fn.LazyDx); reported")
     ap.add_argument("--separate-colsum", action="store_true", help="developer A/B: transposed-conv bias gradients by a separate pass over the gradient instead of the producing launch's statistics; reported")
+    ap.add_argument("--immediate-reduce", action="store_true", help="developer A/B: every weight-gradient launch followed by its own slab reduction instead of the batched reduction at the end of a backward pass; reported")
     ap.add_argument("--composed-losses", action="store_true", help="developer A/B: BCE / L1 loss heads as composed torch ops instead of the one-launch kernels; reported")
     ap.add_argument("--side-stream", action="store_true", help="developer A/B: weight gradients of the small layers on a second stream (measured slower); reported")
     ap.add_argument("--small-norm-grouped", type=int, default=None, help="developer A/B: the same limit for BatchNorm tensors whose statistic groups one workgroup walks in order (forward_pair)")
@@ -422,6 +423,10 @@ def main():
         from unet_bssfp_amd import functional as _Fn3
         _Fn3.LazyDx.enabled = False
         nondefault["eager_final_dx"] = True
+    if a.immediate_reduce:
+        from unet_bssfp_amd import functional as _Fn4
+        _Fn4.DeferredReduce.allowed = False
+        nondefault["immediate_reduce"] = True
     if a.separate_colsum:
         from unet_bssfp_amd import functional as _Fn2
         _Fn2.ColSumSide.enabled = False

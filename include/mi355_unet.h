@@ -239,6 +239,16 @@ int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream);
  * 2x2x2 layers (PatchGAN on space-to-depth operands, UpCat's composite kernel; W >= 32), 1 = tile-form bf16 MFMA kernel,
  * 0 = exact-f32 kernel; -1 = invalid descriptor */
 int mi355_conv_wgrad_plan_kind(const mi355_wgrad_desc* d);
+/* The same weight gradient in two halves, for callers that own a whole backward pass (src/model.py:259-281: nothing reads a
+ * weight's .grad before the optimiser step, or before the bucket's all-reduce under DDP, src/train.py:30-32):
+ * mi355_conv_wgrad_partial launches only the kernel that writes the f32 slabs into d->workspace and fills `job`;
+ * mi355_wgrad_reduce_multi sums the slabs of n such jobs into their dw in ONE launch per 16 jobs (same summation order per job as
+ * mi355_conv_wgrad: bit-identical results).  The caller keeps every job's workspace alive and unmodified until the reduce has
+ * run on the same stream, and two jobs of one call must not address the same dw element (accumulate = 1 jobs add to what
+ * dw held BEFORE the call).  `job` is opaque. */
+typedef struct mi355_wreduce_job { int64_t opaque[20]; } mi355_wreduce_job;
+int mi355_conv_wgrad_partial(const mi355_wgrad_desc* d, mi355_wreduce_job* job, void* stream);
+int mi355_wgrad_reduce_multi(const mi355_wreduce_job* jobs, int32_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Channel statistics and fused normalisation + dropout + LeakyReLU.

@@ -762,6 +762,82 @@ def test_side_stream_weight_gradients_equal_main_stream(hip):
         assert all(torch.equal(a, b) for a, b in zip(out["off"], out[mode])), mode
 
 
+@pytest.mark.parametrize("size", [32, 48])
+def test_deferred_weight_gradient_reduction_is_bit_identical(hip, size):
+    """functional.DeferredReduce (mi355_conv_wgrad_partial + ONE mi355_wgrad_reduce_multi launch per 16 layers at the end of a
+    backward pass) against every weight-gradient launch followed by its own reduction: the same kernel bodies and summation
+    order per layer, so every parameter after four steps is bit-identical, eagerly and under hipGraph replay.  48^3 is not
+    a multiple of 32: the discriminator phase falls back to two calls, every discriminator weight receives two contributions
+    and the second one (accumulating) flushes the pending reductions first."""
+    import unet_bssfp_amd as M
+    from unet_bssfp_amd import functional as Fn
+    from unet_bssfp_amd.functional import DropoutState
+    from unet_bssfp_amd.gan import GraphedTrainingStep, bSSFPToDWITensorModel, synthetic_batch
+    batch = synthetic_batch(2, size, seed=9, device=DEV)
+    out = {}
+    try:
+        for mode in ("immediate", "deferred_eager", "deferred_graph"):
+            Fn.DeferredReduce.allowed = mode != "immediate"
+            n0 = Fn.DeferredReduce.launches
+            torch.manual_seed(4)
+            DropoutState.reset()
+            model = bSSFPToDWITensorModel("bssfp", gen=M.Generator("bssfp", dropout=0.05).to(DEV), discr=M.Discriminator("bssfp").to(DEV)).train()
+            if mode == "deferred_graph":
+                gs = GraphedTrainingStep(model, batch, warmup=2)
+                gs(); gs()
+            else:
+                for i in range(4):
+                    model.training_step(batch, i)
+            torch.cuda.synchronize()
+            assert (Fn.DeferredReduce.launches > n0) == (mode != "immediate")
+            assert not Fn.DeferredReduce._jobs and not Fn.DeferredReduce._after and not Fn.DeferredReduce.enabled
+            out[mode] = [p.detach().clone() for p in model.parameters()]
+    finally:
+        Fn.DeferredReduce.allowed = True
+    for mode in ("deferred_eager", "deferred_graph"):
+        assert all(torch.equal(a, b) for a, b in zip(out["immediate"], out[mode])), mode
+
+
+def test_wgrad_reduce_multi_matches_single_launches(hip):
+    """mi355_wgrad_reduce_multi over a mixed list of jobs (marching 3x3x3, tile-form 3x3x3 with the dense reduce, 1x1x1 streaming,
+    transposed-conv classes, k2 on a space-to-depth operand; more than 16 jobs: two launches) == mi355_conv_wgrad per layer,
+    bit for bit; accumulate = 1 jobs add to what dw held."""
+    from unet_bssfp_amd import ops
+    torch.manual_seed(0)
+    bf = torch.bfloat16
+
+    def act(n, d, c):
+        return ops.as_act(torch.randn(n, d, d, d, c, device=DEV).to(bf))
+    cases = []
+    for (d, ci, co) in ((32, 32, 32), (32, 64, 32), (16, 128, 64), (8, 256, 256), (16, 64, 128)):      # 3x3x3 pad 1
+        cases.append(dict(x=act(1, d, ci), g=act(1, d, co), grid=(d, d, d), ks=3, pad=(1, 1, 1), cout=co, cin=ci,
+                          geo=(ci * 27, 27, (9, 3, 1), (0, 0, 0), (1, 1, 1)), shape=(co, ci, 3, 3, 3), kw={}))
+    for (d, ci, co) in ((64, 32, 16), (16, 64, 32)):                                                  # 1x1x1
+        cases.append(dict(x=act(1, d, ci), g=act(1, d, co), grid=(d, d, d), ks=1, pad=(0, 0, 0), cout=co, cin=ci,
+                          geo=(ci, 1, (1, 1, 1), (0, 0, 0), (1, 1, 1)), shape=(co, ci, 1, 1, 1), kw={}))
+    for (d, ci, co) in ((16, 64, 64), (8, 128, 128)):                                                 # ConvTranspose3d(k2, s2) classes
+        cases.append(dict(x=act(1, d, ci), g=act(1, 2 * d, co), grid=(d, d, d), ks=1, pad=(0, 0, 0), cout=co, cin=ci,
+                          geo=(8, co * 8, (4, 2, 1), (0, 0, 0), (0, 0, 0)), shape=(ci, co, 2, 2, 2), kw=dict(g_cls_cout=co)))
+    cases = cases * 2                                                                                  # 18 jobs
+    outs = []
+    for mode in ("single", "multi"):
+        dws, jobs = [], []
+        for i, c in enumerate(cases):
+            acc = i >= len(cases) // 2
+            dw = torch.full(c["shape"], 0.5 if acc else float("nan"), dtype=torch.float32, device=DEV)
+            ops.conv_wgrad(c["x"], None, c["g"], c["grid"], 1, (0, 0, 0), c["ks"], 1, c["pad"], dw, c["cout"], c["cin"], *c["geo"],
+                           accumulate=acc, defer=jobs if mode == "multi" else None, **c["kw"])
+            dws.append(dw)
+        if mode == "multi":
+            assert len(jobs) == len(cases)
+            ops.wgrad_reduce_multi(jobs)
+        torch.cuda.synchronize()
+        outs.append(dws)
+    for a, b in zip(*outs):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b)
+
+
 def test_gradient_sinks_equal_autograd_accumulation(hip):
     """gradsink.GradBuckets (gradient kernels write parameter gradients in place, second uses accumulate in the kernel) must
     give the same gradients and the same parameters after two steps as plain autograd accumulation (.grad tensors created by

@@ -49,6 +49,10 @@ class WgradDesc(C.Structure):
                 ("g_cls_cout", _i32), ("xn", _i32)]
 
 
+class WreduceJob(C.Structure):
+    _fields_ = [("opaque", _i64 * 20)]
+
+
 class NormActDesc(C.Structure):
     _fields_ = [("z", _vp), ("ldz", _i32), ("a", _vp), ("lda", _i32), ("c", _i32),
                 ("rows_per_group", _i64), ("groups", _i32),
@@ -92,6 +96,8 @@ _SIGNATURES = {
     "mi355_conv_wgrad_workspace": (_i64, [C.POINTER(WgradDesc)]),
     "mi355_conv_wgrad_plan_kind": (C.c_int, [C.POINTER(WgradDesc)]),
     "mi355_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc), _vp]),
+    "mi355_conv_wgrad_partial": (C.c_int, [C.POINTER(WgradDesc), C.POINTER(WreduceJob), _vp]),
+    "mi355_wgrad_reduce_multi": (C.c_int, [C.POINTER(WreduceJob), _i32, _vp]),
     "mi355_channel_stats": (C.c_int, [_vp, _i32, _i32, _i64, _i32, _vp, _i32, _i32, _vp]),
     "mi355_channel_stats_blocks": (_i32, [_i64]),
     "mi355_norm_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i64, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _f32, _vp, _vp]),

@@ -10,6 +10,7 @@
 // scatters into the torch weight layout.
 #include "common.h"
 #include <type_traits>
+#include <cstring>
 
 namespace {
 
@@ -128,13 +129,16 @@ __device__ __forceinline__ float4 ld_once(const float* p) {
 }
 // F4 float4 groups x SL slab lanes per block (F4 * SL = 256): 32 x 8 for ordinary layers; 8 x 32 when a layer has
 // so few weights (1x1x1 convs: 1024 elements under 2048 slabs) that 128-element blocks would leave 8 blocks.
+// (the three reduce forms are __device__ bodies over a caller-provided LDS area and block coordinates: the single-layer kernels
+//  below and wgrad_reduce_multi_kernel -- the slabs of up to 16 layers in one launch -- run the same code)
+constexpr int kRedLdsFloats = 32 * (4 * 64 + 1);                     // the largest form (space-to-depth patch): 32.1 KB
 template <int F4, int SL>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WreduceArgs a) {
+__device__ __forceinline__ void wgrad_reduce_body(const WreduceArgs& a, const int bx, float* smem) {
   static_assert(F4 * SL == 256, "block shape");
-  __shared__ float4 red[SL][F4];
+  float4 (*red)[F4] = reinterpret_cast<float4 (*)[F4]>(smem);         // [SL][F4]
   const long long per = (long long)a.ntaps * a.cinp * a.coutp;        // multiple of 1024
   const int e = threadIdx.x % F4, sl = threadIdx.x / F4;
-  const long long idx = ((long long)blockIdx.x * F4 + e) * 4;
+  const long long idx = ((long long)bx * F4 + e) * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (idx < per) {
     const float* base = a.slab + idx;
@@ -177,6 +181,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WreduceArgs a) 
     if (a.accumulate) a.dw[dst] += f[j]; else a.dw[dst] = f[j];
   }
 }
+template <int F4, int SL>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WreduceArgs a) {
+  __shared__ float4 red[SL * F4];
+  wgrad_reduce_body<F4, SL>(a, blockIdx.x, reinterpret_cast<float*>(red));
+}
 
 
 // Few slabs, many weights (the 8^3 / 16^3 levels: 2-16 slabs of up to 28 MB): the cost is the WRITE side --
@@ -190,13 +199,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WreduceArgs a) 
 // before the first add (nslabs <= 16: up to 64 loads in flight; the 4-byte form with one slab at a time read its 14 - 56 MB of
 // slabs at 1.4 TB/s: 16 - 27 us per layer).  Summation in slab order: bit-identical to the form it replaces.
 template <int NT, int CIB>
-__global__ __launch_bounds__(256) void wgrad_reduce_dense_kernel(const WreduceArgs a) {
+__device__ __forceinline__ void wgrad_reduce_dense_body(const WreduceArgs& a, const int bx, const int by, float* tile) {
   constexpr int ROW = CIB * NT + 1;                       // LDS row of one output channel: [ci][tap] (+1: odd stride)
   constexpr int ITEMS = CIB * NT;                         // (ci, tap) pairs of the patch; 8 threads (co quads) per pair
   constexpr int PER = (ITEMS + 31) / 32;                  // pairs per thread
-  __shared__ float tile[32 * ROW];
+  static_assert(32 * ROW <= kRedLdsFloats, "LDS area");
   const int t = threadIdx.x, cq = t & 7, grp = t >> 3;    // co quad, pair lane (32 of them)
-  const int ci0 = blockIdx.x * CIB, co0 = blockIdx.y * 32;
+  const int ci0 = bx * CIB, co0 = by * 32;
   const long long per = (long long)NT * a.cinp * a.coutp;
   const long long tstride = (long long)a.cinp * a.coutp;
   float4 s[PER];
@@ -240,17 +249,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_dense_kernel(const WreduceAr
     }
   }
 }
+template <int NT, int CIB>
+__global__ __launch_bounds__(256) void wgrad_reduce_dense_kernel(const WreduceArgs a) {
+  __shared__ float tile[32 * (CIB * NT + 1)];
+  wgrad_reduce_dense_body<NT, CIB>(a, blockIdx.x, blockIdx.y, tile);
+}
 
 // The PatchGAN k4 s2 layers computed on space-to-depth tensors: slab rows are (j, blk * cp + c) with 8 dense
 // taps j and 8 parity blocks blk, and dw[co][c][kd][kh][kw] has kd = 2 jd + bd (likewise h, w): for one (co, c)
 // the 8 x 8 (j, blk) values are the 64 contiguous taps of the 4x4x4 kernel.  The generic kernel scattered them as
 // 4-byte stores (101 us for the 256->512 layer, whose "reduce" has a single slab); here a block turns a
 // 4 (c) x 32 (co) x 64 patch through LDS and writes 256 contiguous floats per output channel.
-__global__ __launch_bounds__(256) void wgrad_reduce_s2d_kernel(const WreduceArgs a) {
+__device__ __forceinline__ void wgrad_reduce_s2d_body(const WreduceArgs& a, const int bx, const int by, float* tile) {
   constexpr int CB = 4, ROW = CB * 64 + 1;
-  __shared__ float tile[32 * ROW];
+  static_assert(32 * ROW <= kRedLdsFloats, "LDS area");
   const int t = threadIdx.x, co_l = t & 31, j = t >> 5;                    // j = dense tap of the k2 formulation
-  const int c0 = blockIdx.x * CB, co0 = blockIdx.y * 32;
+  const int c0 = bx * CB, co0 = by * 32;
   const long long per = (long long)8 * a.cinp * a.coutp;
   float s[8][CB];
 #pragma unroll
@@ -284,6 +298,38 @@ __global__ __launch_bounds__(256) void wgrad_reduce_s2d_kernel(const WreduceArgs
       const float v = tile[r * ROW + i];
       if (a.accumulate) dst[i] += v; else dst[i] = v;
     }
+  }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_s2d_kernel(const WreduceArgs a) {
+  __shared__ float tile[kRedLdsFloats];
+  wgrad_reduce_s2d_body(a, blockIdx.x, blockIdx.y, tile);
+}
+
+// Slab reductions of up to kRedChunk layers in ONE launch (mi355_wgrad_reduce_multi): a step has ~30 weight-gradient
+// launches, each followed by a 7 - 23 us reduction of its slabs that nothing but the optimiser (or the bucket's all-reduce)
+// waits for; deferred to the end of a backward segment they are one launch.  Block -> (job, block of the job) through
+// the prefix table; each job runs the form (and so the summation order) its own launch would: bit-identical results.
+constexpr int kRedChunk = 16;
+enum { kRedGeneric = 0, kRedGenericNarrow, kRedDense27_8, kRedDense27_4, kRedDense27_2, kRedDense1_8, kRedDense1_4, kRedDense1_2, kRedS2d };
+struct WreduceMulti { WreduceArgs a[kRedChunk]; int kind[kRedChunk], gx[kRedChunk], first[kRedChunk + 1]; int n; };
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const WreduceMulti m) {
+  __shared__ float smem[kRedLdsFloats];
+  const int b = blockIdx.x;
+  int j = 0;
+  while (j + 1 < m.n && b >= m.first[j + 1]) ++j;
+  const int local = b - m.first[j], gx = m.gx[j];
+  const int bx = local % gx, by = local / gx;
+  const WreduceArgs& a = m.a[j];
+  switch (m.kind[j]) {
+    case kRedGeneric: wgrad_reduce_body<32, 8>(a, local, smem); break;
+    case kRedGenericNarrow: wgrad_reduce_body<8, 32>(a, local, smem); break;
+    case kRedDense27_8: wgrad_reduce_dense_body<27, 8>(a, bx, by, smem); break;
+    case kRedDense27_4: wgrad_reduce_dense_body<27, 4>(a, bx, by, smem); break;
+    case kRedDense27_2: wgrad_reduce_dense_body<27, 2>(a, bx, by, smem); break;
+    case kRedDense1_8: wgrad_reduce_dense_body<1, 8>(a, bx, by, smem); break;
+    case kRedDense1_4: wgrad_reduce_dense_body<1, 4>(a, bx, by, smem); break;
+    case kRedDense1_2: wgrad_reduce_dense_body<1, 2>(a, bx, by, smem); break;
+    default: wgrad_reduce_s2d_body(a, bx, by, smem); break;
   }
 }
 
@@ -1158,6 +1204,64 @@ void launch_wgrad(const WgradArgs& a, const WPlan& p, hipStream_t st) {
   }
 }
 
+constexpr int kRedMagic = 0x52454431;                                 // "RED1"
+struct RedJob { WreduceArgs q; int kind, gx, gy, magic; };            // what mi355_wreduce_job holds
+
+void make_reduce_job(const mi355_wgrad_desc* d, const WPlan& p, RedJob* job) {
+  WreduceArgs& q = job->q;
+  q.slab = d->workspace; q.nslabs = p.nslabs; q.ks = d->ks; q.ntaps = d->ks * d->ks * d->ks;
+  q.cinp = p.cinp32; q.coutp = p.coutp32;
+  q.dw = d->dw; q.cout = d->cout; q.cin = d->cin;
+  q.s_co = d->s_co; q.s_ci = d->s_ci; q.s_k0 = d->s_k[0]; q.s_k1 = d->s_k[1]; q.s_k2 = d->s_k[2];
+  q.tb0 = d->tbase[0]; q.tb1 = d->tbase[1]; q.tb2 = d->tbase[2];
+  q.ts0 = d->tstep[0]; q.ts1 = d->tstep[1]; q.ts2 = d->tstep[2];
+  q.accumulate = d->accumulate;
+  q.s2d_cp = d->s2d_cp;
+  q.co_cls = d->g_cls_cout;
+  job->magic = kRedMagic;
+  const long long per = (long long)q.ntaps * q.cinp * q.coutp;
+  const int k3 = d->ks * d->ks * d->ks;
+  const bool dense = !q.s2d_cp && !q.co_cls && q.s_k2 == 1 && q.s_k1 == d->ks && q.s_k0 == d->ks * d->ks && q.s_ci == k3 &&
+                     q.tb0 == 0 && q.tb1 == 0 && q.tb2 == 0 && q.ts0 == 1 && q.ts1 == 1 && q.ts2 == 1;
+  if (dense && q.nslabs <= 16 && (d->ks == 3 || d->ks == 1) && q.cinp % 8 == 0 && q.coutp % 32 == 0) {
+    // input channels per block: as many as keep >= 512 blocks in flight
+    const long long cob = q.coutp / 32;
+    const int cib = (q.cinp / 8) * cob >= 512 ? 8 : ((q.cinp / 4) * cob >= 512 ? 4 : 2);
+    job->gx = q.cinp / cib; job->gy = (int)cob;
+    job->kind = (d->ks == 3 ? kRedDense27_8 : kRedDense1_8) + (cib == 8 ? 0 : (cib == 4 ? 1 : 2));
+    return;
+  }
+  const bool s2d_dense = q.s2d_cp > 0 && !q.co_cls && d->ks == 2 && q.s_k2 == 1 && q.s_k1 == 4 && q.s_k0 == 16 && q.s_ci == 64 &&
+                         q.tb0 == 0 && q.tb1 == 0 && q.tb2 == 0 && q.ts0 == 2 && q.ts1 == 2 && q.ts2 == 2 &&
+                         q.cinp == 8 * q.s2d_cp && q.s2d_cp % 4 == 0 && q.coutp % 32 == 0;
+  if (s2d_dense && q.nslabs <= 8) {
+    job->kind = kRedS2d; job->gx = q.s2d_cp / 4; job->gy = q.coutp / 32;
+    return;
+  }
+  job->gy = 1;
+  if (per <= 16384 && q.nslabs >= 128) { job->kind = kRedGenericNarrow; job->gx = (int)((per + 31) / 32); }
+  else { job->kind = kRedGeneric; job->gx = (int)((per + 127) / 128); }
+}
+
+int launch_reduce_single(const RedJob& job, hipStream_t st) {
+  const WreduceArgs& q = job.q;
+  const dim3 grid((unsigned)job.gx, (unsigned)job.gy);
+  switch (job.kind) {
+    case kRedGeneric: wgrad_reduce_kernel<32, 8><<<grid, dim3(256), 0, st>>>(q); return mi355_check_launch("wgrad_reduce");
+    case kRedGenericNarrow: wgrad_reduce_kernel<8, 32><<<grid, dim3(256), 0, st>>>(q); return mi355_check_launch("wgrad_reduce");
+    case kRedDense27_8: wgrad_reduce_dense_kernel<27, 8><<<grid, dim3(256), 0, st>>>(q); break;
+    case kRedDense27_4: wgrad_reduce_dense_kernel<27, 4><<<grid, dim3(256), 0, st>>>(q); break;
+    case kRedDense27_2: wgrad_reduce_dense_kernel<27, 2><<<grid, dim3(256), 0, st>>>(q); break;
+    case kRedDense1_8: wgrad_reduce_dense_kernel<1, 8><<<grid, dim3(256), 0, st>>>(q); break;
+    case kRedDense1_4: wgrad_reduce_dense_kernel<1, 4><<<grid, dim3(256), 0, st>>>(q); break;
+    case kRedDense1_2: wgrad_reduce_dense_kernel<1, 2><<<grid, dim3(256), 0, st>>>(q); break;
+    default: wgrad_reduce_s2d_kernel<<<grid, dim3(256), 0, st>>>(q); return mi355_check_launch("wgrad_reduce_s2d");
+  }
+  return mi355_check_launch("wgrad_reduce_dense");
+}
+
+int conv_wgrad_impl(const mi355_wgrad_desc* d, mi355_wreduce_job* deferred, void* stream);
+
 }  // namespace
 
 extern "C" int64_t mi355_conv_wgrad_workspace(const mi355_wgrad_desc* d) {
@@ -1172,7 +1276,8 @@ extern "C" int mi355_conv_wgrad_plan_kind(const mi355_wgrad_desc* d) {
   return p.march ? 2 : (p.pw ? 3 : (p.march2 ? 4 : (p.fast ? 1 : 0)));
 }
 
-extern "C" int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream) {
+namespace {
+int conv_wgrad_impl(const mi355_wgrad_desc* d, mi355_wreduce_job* deferred, void* stream) {
   WPlan p;
   int rc = wplan(d, &p);
   if (rc) return rc;
@@ -1229,43 +1334,47 @@ extern "C" int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream) {
   else launch_wgrad<bf16_t>(a, p, st);
   rc = mi355_check_launch("conv_wgrad");
   if (rc) return rc;
-  WreduceArgs q;
-  q.slab = d->workspace; q.nslabs = p.nslabs; q.ks = d->ks; q.ntaps = d->ks * d->ks * d->ks;
-  q.cinp = p.cinp32; q.coutp = p.coutp32;
-  q.dw = d->dw; q.cout = d->cout; q.cin = d->cin;
-  q.s_co = d->s_co; q.s_ci = d->s_ci; q.s_k0 = d->s_k[0]; q.s_k1 = d->s_k[1]; q.s_k2 = d->s_k[2];
-  q.tb0 = d->tbase[0]; q.tb1 = d->tbase[1]; q.tb2 = d->tbase[2];
-  q.ts0 = d->tstep[0]; q.ts1 = d->tstep[1]; q.ts2 = d->tstep[2];
-  q.accumulate = d->accumulate;
-  q.s2d_cp = d->s2d_cp;
-  q.co_cls = d->g_cls_cout;
-  const long long per = (long long)q.ntaps * q.cinp * q.coutp;
-  const int k3 = d->ks * d->ks * d->ks;
-  const bool dense = !q.s2d_cp && !q.co_cls && q.s_k2 == 1 && q.s_k1 == d->ks && q.s_k0 == d->ks * d->ks && q.s_ci == k3 &&
-                     q.tb0 == 0 && q.tb1 == 0 && q.tb2 == 0 && q.ts0 == 1 && q.ts1 == 1 && q.ts2 == 1;
-  if (dense && q.nslabs <= 16 && (d->ks == 3 || d->ks == 1) && q.cinp % 8 == 0 && q.coutp % 32 == 0) {
-    // input channels per block: as many as keep >= 512 blocks in flight
-    const long long cob = q.coutp / 32;
-    const int cib = (q.cinp / 8) * cob >= 512 ? 8 : ((q.cinp / 4) * cob >= 512 ? 4 : 2);
-    const dim3 grid((unsigned)(q.cinp / cib), (unsigned)cob);
-#define DENSE(NT)                                                                           \
-    do {                                                                                    \
-      if (cib == 8) wgrad_reduce_dense_kernel<NT, 8><<<grid, dim3(256), 0, st>>>(q);        \
-      else if (cib == 4) wgrad_reduce_dense_kernel<NT, 4><<<grid, dim3(256), 0, st>>>(q);   \
-      else wgrad_reduce_dense_kernel<NT, 2><<<grid, dim3(256), 0, st>>>(q);                 \
-    } while (0)
-    if (d->ks == 3) DENSE(27); else DENSE(1);
-#undef DENSE
-    return mi355_check_launch("wgrad_reduce_dense");
+  RedJob job;
+  make_reduce_job(d, p, &job);
+  if (deferred) {
+    static_assert(sizeof(RedJob) <= sizeof(mi355_wreduce_job), "mi355_wreduce_job is too small");
+    memset(deferred, 0, sizeof(*deferred));
+    memcpy(deferred, &job, sizeof(job));
+    return MI355_OK;
   }
-  const bool s2d_dense = q.s2d_cp > 0 && !q.co_cls && d->ks == 2 && q.s_k2 == 1 && q.s_k1 == 4 && q.s_k0 == 16 && q.s_ci == 64 &&
-                         q.tb0 == 0 && q.tb1 == 0 && q.tb2 == 0 && q.ts0 == 2 && q.ts1 == 2 && q.ts2 == 2 &&
-                         q.cinp == 8 * q.s2d_cp && q.s2d_cp % 4 == 0 && q.coutp % 32 == 0;
-  if (s2d_dense && q.nslabs <= 8) {
-    wgrad_reduce_s2d_kernel<<<dim3((unsigned)(q.s2d_cp / 4), (unsigned)(q.coutp / 32)), dim3(256), 0, st>>>(q);
-    return mi355_check_launch("wgrad_reduce_s2d");
+  return launch_reduce_single(job, st);
+}
+
+}  // namespace
+
+extern "C" int mi355_conv_wgrad(const mi355_wgrad_desc* d, void* stream) { return conv_wgrad_impl(d, nullptr, stream); }
+
+extern "C" int mi355_conv_wgrad_partial(const mi355_wgrad_desc* d, mi355_wreduce_job* job, void* stream) {
+  MI355_REQUIRE(job, "wgrad_partial: null job");
+  return conv_wgrad_impl(d, job, stream);
+}
+
+extern "C" int mi355_wgrad_reduce_multi(const mi355_wreduce_job* jobs, int32_t n, void* stream) {
+  MI355_REQUIRE(n >= 0 && (n == 0 || jobs), "wgrad_reduce_multi: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  for (int j0 = 0; j0 < n; j0 += kRedChunk) {
+    WreduceMulti m;
+    m.n = std::min(kRedChunk, n - j0);
+    long long blocks = 0;
+    for (int j = 0; j < kRedChunk; ++j) {
+      RedJob job;
+      memcpy(&job, jobs + j0 + std::min(j, m.n - 1), sizeof(job));      // (unused entries repeat the last job; never selected)
+      MI355_REQUIRE(job.magic == kRedMagic && job.kind >= kRedGeneric && job.kind <= kRedS2d && job.gx > 0 && job.gy > 0,
+                    "wgrad_reduce_multi: job %d was not filled by mi355_conv_wgrad_partial", j0 + j);
+      m.a[j] = job.q; m.kind[j] = job.kind; m.gx[j] = job.gx;
+      m.first[j] = (int)blocks;
+      if (j < m.n) blocks += (long long)job.gx * job.gy;
+    }
+    m.first[kRedChunk] = (int)blocks;
+    MI355_REQUIRE(blocks > 0 && blocks < (1ll << 31), "wgrad_reduce_multi: bad block count");
+    wgrad_reduce_multi_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(m);
+    const int rc = mi355_check_launch("wgrad_reduce_multi");
+    if (rc) return rc;
   }
-  if (per <= 16384 && q.nslabs >= 128) wgrad_reduce_kernel<8, 32><<<dim3((unsigned)((per + 31) / 32)), dim3(256), 0, st>>>(q);
-  else wgrad_reduce_kernel<32, 8><<<dim3((unsigned)((per + 127) / 128)), dim3(256), 0, st>>>(q);
-  return mi355_check_launch("wgrad_reduce");
+  return MI355_OK;
 }

@@ -193,6 +193,69 @@ class SideStream:
                                 # edges of ~70 small launches cost more than the overlap returns; bench.py --side-stream turns it on
 
 
+class DeferredReduce:
+    """Slab reductions of the weight-gradient launches, deferred and batched (round 4).  Every weight-gradient kernel writes f32
+    partial sums (slabs) that a second launch sums into ``weight.grad`` -- ~30 launches of 7 - 23 us per step that nothing in
+    the backward pass waits for: only the optimiser (and, under DDP, the bucket's all-reduce) reads a weight gradient.  Inside
+    ``scope()`` (the harness's ``manual_backward``) the layers launch only their slab kernel (``mi355_conv_wgrad_partial``) and
+    the reductions of up to ``max_jobs`` layers run as ONE launch (``mi355_wgrad_reduce_multi``): when that many are pending,
+    when a layer contributes a second time in the pass, and when the scope ends.  ``GradBuckets.written`` is called at
+    the flush, so a bucket is exchanged only after its reductions have been enqueued.  Same kernels bodies and summation
+    order per layer as the immediate form: bit-identical gradients (``test_deferred_weight_gradient_reduction_is_bit_identical``).
+    Outside a scope (op-level use, ``loss.backward()`` on a bare network) nothing is deferred."""
+    enabled = False
+    allowed = True              # bench.py --immediate-reduce turns it off (A/B)
+    max_jobs = 16               # one launch of mi355_wgrad_reduce_multi
+    _jobs = []                  # (job, workspace) pairs: the workspace stays allocated until its reduction is enqueued
+    _after = []                 # (sink, parameter): GradBuckets.written calls owed at the flush
+    _params = set()
+    launches = 0                # multi-launches so far (tests)
+
+    @classmethod
+    def wants(cls, sink, param, acc) -> bool:
+        """True: this contribution may be deferred.  A second contribution to a parameter that still has a pending reduction
+        flushes first (its ``fresh`` state is only advanced by ``written``) and runs immediately, accumulating."""
+        if not cls.enabled or sink is None:
+            return False
+        if acc or id(param) in cls._params:
+            cls.flush()
+            return False
+        return True
+
+    @classmethod
+    def add(cls, jobs, sink, param):
+        cls._jobs.extend(jobs)
+        cls._after.append((sink, param))
+        cls._params.add(id(param))
+        if len(cls._jobs) + 2 > cls.max_jobs:       # (a layer adds at most two jobs)
+            cls.flush()
+
+    @classmethod
+    def flush(cls):
+        if not cls._jobs and not cls._after:
+            return
+        jobs, after = cls._jobs, cls._after
+        cls._jobs, cls._after, cls._params = [], [], set()     # (written() may launch a bucket, whose launch flushes: re-entrant)
+        ops.wgrad_reduce_multi(jobs)
+        cls.launches += 1
+        for sink, param in after:
+            sink.written(param)
+
+    class scope:
+        def __enter__(self):
+            self.prev = DeferredReduce.enabled
+            DeferredReduce.enabled = DeferredReduce.allowed
+            return self
+
+        def __exit__(self, *exc):
+            if exc[0] is None:
+                DeferredReduce.flush()
+            else:                                   # a failed backward pass: drop what is pending
+                DeferredReduce._jobs, DeferredReduce._after, DeferredReduce._params = [], [], set()
+            DeferredReduce.enabled = self.prev
+            return False
+
+
 # ====================================================================================== layout
 class Fp8Scales:
     """Delayed per-tensor scaling of the e4m3 operands (BASELINE.json configs[4]).  An operand's scale 224 / amax has to be
@@ -777,20 +840,27 @@ class ConvFn(Function):
             acc = wsink is not None and not wsink.fresh(weight)
             dwt = sink_grad(weight) if wsink is not None else torch.empty_like(weight, dtype=torch.float32)
 
+            defer = [] if (not side and DeferredReduce.wants(wsink, weight, acc)) else None
+            if defer is None and wsink is not None:
+                acc = not wsink.fresh(weight)              # (wants() may have flushed this parameter's first contribution)
+
             def wgrad():
                 if ctx.s2d_cp:
                     ops.conv_wgrad(x0, None, dz, (do_, ho, wo), 1, (0, 0, 0), 2, 1, (0, 0, 0), dwt, spec.cout, spec.cin,
-                                   spec.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (2, 2, 2), s2d_cp=ctx.s2d_cp, accumulate=acc)
+                                   spec.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (2, 2, 2), s2d_cp=ctx.s2d_cp, accumulate=acc,
+                                   defer=defer)
                 elif spec.kind == "conv":
                     ops.conv_wgrad(x0, x1, dz, (do_, ho, wo), 1, (0, 0, 0), k, spec.stride, (spec.pad,) * 3, dwt,
-                                   spec.cout, spec.cin, spec.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (1, 1, 1), accumulate=acc)
+                                   spec.cout, spec.cin, spec.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (1, 1, 1), accumulate=acc,
+                                   defer=defer)
                 elif dtype == torch.bfloat16 and spec.cout % 32 == 0 and cg == spec.cout:
                     # transposed conv: the 8 classes are 8*Cout GEMM columns of one k=1 weight-gradient launch
                     ops.conv_wgrad(x0, None, dz, (di, hi, wi), 1, (0, 0, 0), 1, 1, (0, 0, 0), dwt,
                                    spec.cout, spec.cin, 8, spec.cout * 8, (4, 2, 1), (0, 0, 0), (0, 0, 0),
-                                   g_cls_cout=spec.cout, accumulate=acc)
+                                   g_cls_cout=spec.cout, accumulate=acc, defer=defer)
                 else:
-                    for cls in CLASSES8:
+                    assert defer is None or not defer
+                    for cls in CLASSES8:                   # (eight launches into one workspace each: never deferred)
                         ops.conv_wgrad(x0, None, dz, (di, hi, wi), 2, cls, 1, 1, (0, 0, 0), dwt,
                                        spec.cout, spec.cin, 8, spec.cout * 8, (4, 2, 1), cls, (0, 0, 0), accumulate=acc)
 
@@ -798,7 +868,9 @@ class ConvFn(Function):
                 SideStream.run(wgrad, x0, x1, dz)
             else:
                 wgrad()
-            if wsink is not None:
+            if defer:
+                DeferredReduce.add(defer, wsink, weight)
+            elif wsink is not None:
                 wsink.written(weight)
             else:
                 dw = dwt
@@ -922,16 +994,22 @@ class SplitS2dConvFn(Function):
             dwt = sink_grad(weight) if wsink is not None else torch.empty_like(weight, dtype=torch.float32)
             geo = (spec.cin * k ** 3, k ** 3, (k * k, k, 1), (0, 0, 0), (2, 2, 2))
             nx = sx.shape[0]
+            defer = [] if DeferredReduce.wants(wsink, weight, acc) else None   # (x- and y-part: disjoint channel slices of dw)
+            if defer is None and wsink is not None:
+                acc = not wsink.fresh(weight)
             if ny == 2 * nx and SplitS2dConvFn.sum_pair_gradients:
                 # both halves of a stacked pair saw the SAME x: x (*) dz_a + x (*) dz_b = x (*) (dz_a + dz_b) -- half the x-part's
                 # weight-gradient work for one pass over the two gradients (the sum is formed in f32 and rounded to bf16 once)
                 ops.conv_wgrad(sx, None, torch.add(dz[:nx], dz[nx:]), grid, 1, (0, 0, 0), 2, 1, (0, 0, 0), dwt, spec.cout, cx, *geo,
-                               s2d_cp=cpx, accumulate=acc)
+                               s2d_cp=cpx, accumulate=acc, defer=defer)
             else:
-                ops.conv_wgrad(sx, None, dz, grid, 1, (0, 0, 0), 2, 1, (0, 0, 0), dwt, spec.cout, cx, *geo, s2d_cp=cpx, accumulate=acc, n=ny)
+                ops.conv_wgrad(sx, None, dz, grid, 1, (0, 0, 0), 2, 1, (0, 0, 0), dwt, spec.cout, cx, *geo, s2d_cp=cpx, accumulate=acc, n=ny,
+                               defer=defer)
             ops.conv_wgrad(sy, None, dz, grid, 1, (0, 0, 0), 2, 1, (0, 0, 0), dwt, spec.cout, cy, *geo, s2d_cp=cpy, accumulate=acc,
-                           dw_offset=cx * k ** 3)
-            if wsink is not None:
+                           dw_offset=cx * k ** 3, defer=defer)
+            if defer:
+                DeferredReduce.add(defer, wsink, weight)
+            elif wsink is not None:
                 wsink.written(weight)
             else:
                 dw = dwt

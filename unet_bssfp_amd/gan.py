@@ -256,7 +256,10 @@ class bSSFPToDWITensorModel(nn.Module):
         fn = sys.modules.get(__package__ + ".functional")
         if fn is None or self.sinks_gen is None:
             return contextlib.nullcontext()
-        return fn.SideStream.scope()
+        stack = contextlib.ExitStack()
+        stack.enter_context(fn.SideStream.scope())
+        stack.enter_context(fn.DeferredReduce.scope())      # slab reductions of the pass batched into a few launches (exits first)
+        return stack
 
     @staticmethod
     def _close_stage_boundary():

@@ -33,6 +33,7 @@ def _join_side_stream():
     import sys
     fn = sys.modules.get(__package__ + ".functional")
     if fn is not None:
+        fn.DeferredReduce.flush()                    # pending slab reductions write into the buckets as well
         fn.SideStream.join()
 
 

@@ -293,10 +293,12 @@ WGRAD_PROBE = None      # tests: called as probe(plan kind, desc) before a weigh
 
 
 def conv_wgrad(x0, x1, g, grid, gs, goff, ks, stride, pad, dw, cout, cin, s_co, s_ci, s_k, tbase, tstep,
-               accumulate=False, s2d_cp=0, g_cls_cout=0, dw_offset=0, n=None):
+               accumulate=False, s2d_cp=0, g_cls_cout=0, dw_offset=0, n=None, defer=None):
     """dw (torch layout, f32) (+)= sum_p x[p*stride+tap-pad] * g[p*gs+goff].
     dw_offset: element offset into dw (a channel slice of a layer's weight); n: samples of the grid when x0 holds fewer
-    (x sample = grid sample % x0.shape[0]: one input under several gradients)."""
+    (x sample = grid sample % x0.shape[0]: one input under several gradients).
+    defer: a list -- only the slab-producing kernel is launched and (job, workspace) is appended; ``wgrad_reduce_multi``
+    sums the slabs of many layers in one launch later (dw is NOT valid before that)."""
     require_cuda(x0, x1, g, dw)
     assert dw.dtype == torch.float32 and g.dtype == x0.dtype
     d = _lib.WgradDesc()
@@ -333,7 +335,20 @@ def conv_wgrad(x0, x1, g, grid, gs, goff, ks, stride, pad, dw, cout, cin, s_co, 
         WGRAD_PROBE(lib.mi355_conv_wgrad_plan_kind(C.byref(d)), d)
     ws = torch.empty((need // 4,), dtype=torch.float32, device=x0.device)
     d.workspace, d.workspace_bytes = ws.data_ptr(), need
+    if defer is not None:
+        job = _lib.WreduceJob()
+        _lib.check(lib.mi355_conv_wgrad_partial(C.byref(d), C.byref(job), _stream()), "conv_wgrad_partial")
+        defer.append((job, ws))
+        return
     _lib.check(lib.mi355_conv_wgrad(C.byref(d), _stream()), "conv_wgrad")
+
+
+def wgrad_reduce_multi(jobs):
+    """jobs: the (job, workspace) pairs ``conv_wgrad(..., defer=list)`` appended; one launch per 16 of them."""
+    if not jobs:
+        return
+    arr = (_lib.WreduceJob * len(jobs))(*[j for j, _ in jobs])
+    _lib.check(_lib.load().mi355_wgrad_reduce_multi(arr, len(jobs), _stream()), "wgrad_reduce_multi")
 
 
 # ------------------------------------------------------------------------------ UpCat's up-branch as one transposed convolution
