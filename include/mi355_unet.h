@@ -313,6 +313,14 @@ typedef struct mi355_normact_desc {
    * (rows of ldfy elements); skip_a = 1: a itself is not stored (a no-grad pass whose only consumer of a is that convolution).
    * Saves the convolution's launch and its 134-MB read of a at 128^3. */
   void* fy; int32_t ldfy; int32_t fcp; const float* fbias; int32_t skip_a;
+  /* optional, backward (bwd_reduce / bwd_apply): `da` is NOT materialised by a max-pool backward launch -- a was consumed by
+   * MaxPool3d(2) (MONAI BasicUNet's Down blocks, src/model.py:22-28) and, optionally, by a skip connection whose gradient is `da`
+   * (NULL: none): da[v][ch] = (pool_idx[o][ch] == k ? pool_dy[o][ch] : 0) + da[v][ch], rounded to `dtype`, where v = (n, d, h, w) on the
+   * sd x sh x sw grid (even extents), o = (n, d/2, h/2, w/2) and k = 4 (d&1) + 2 (h&1) + (w&1); pool_idx = the window positions
+   * mi355_maxpool2_fwd_idx recorded ([rows/8][c] bytes), pool_dy = the pooled tensor's gradient (rows of ldpdy elements).
+   * Bit-identical to mi355_maxpool2_bwd(_add) followed by the plain kernels; saves that launch's 134-MB write and 3 x 134 MB of
+   * reads per backward pass at 128^3 x 32. */
+  const void* pool_idx; const void* pool_dy; int32_t ldpdy;
 } mi355_normact_desc;
 int mi355_normact_fwd(const mi355_normact_desc* d, void* stream);
 int mi355_normact_bwd_reduce(const mi355_normact_desc* d, void* stream);
@@ -364,6 +372,10 @@ int mi355_colsum_finalize_from(const float* part, int32_t parts, int32_t c, int3
  * ---------------------------------------------------------------------------------------- */
 int mi355_maxpool2_fwd(const void* x, int32_t ldx, void* y, int32_t ldy, int32_t n, int32_t c,
                        int32_t d, int32_t h, int32_t w, int32_t dtype, void* stream);
+/* the same, also recording for every pooled element the window position (4 kd + 2 kh + kw, one byte, idx[(n,od,oh,ow)][c]) the
+ * backward pass routes its gradient to -- what mi355_normact_desc::pool_idx reads instead of a max-pool backward launch */
+int mi355_maxpool2_fwd_idx(const void* x, int32_t ldx, void* y, int32_t ldy, uint8_t* idx, int32_t n, int32_t c,
+                           int32_t d, int32_t h, int32_t w, int32_t dtype, void* stream);
 int mi355_maxpool2_bwd(const void* x, int32_t ldx, const void* y, int32_t ldy,
                        const void* dy, int32_t lddy, void* dx, int32_t lddx,
                        int32_t n, int32_t c, int32_t d, int32_t h, int32_t w,

@@ -5,6 +5,7 @@
 //   W48   ds_write_b128, piece p = tid -> (p >> 1) * 48 + (p & 1) * 16   conv_lowg's halo / weight-slot writes (round 3)
 //   W48R  ds_write_b128, lane j of a 32-lane half -> voxel (j & 15), half (j >> 4)   the same bytes, lanes permuted so that 16
 //         consecutive lanes write 16 different 16-byte bank groups (the read pattern's property)
+//   R48x2 / R48x4  conv_lowg's HALO fragment reads: 32 voxels as 2 rows of 16 (tile 4x8x16) / 4 rows of 8 (tile 8x8x8)
 //   RL16  ds_read_b128, lane * 16 (the trivially conflict-free reference)      WL16  ds_write_b128, lane * 16
 // Prints cycles (s_memtime) per instruction of wave 0 of block 0; run it a second time under
 //   rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT --kernel-trace
@@ -25,7 +26,10 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, long long* cyc, int 
   if (MODE == 0) off = r * 48 + h * 16 + wave * 3072;
   else if (MODE == 1) off = (tid >> 1) * 48 + (tid & 1) * 16;
   else if (MODE == 2) { const int j = tid & 31, g = tid >> 5; off = (g * 16 + (j & 15)) * 48 + (j >> 4) * 16; }
+  else if (MODE == 5) off = ((r >> 4) * 18 + (r & 15)) * 48 + h * 16 + wave * 3072;   // two rows of 16 voxels, halo row pitch 18 (TW = 16)
+  else if (MODE == 6) off = ((r >> 3) * 10 + (r & 7)) * 48 + h * 16 + wave * 3072;     // four rows of 8 voxels, halo row pitch 10 (TW = 8)
   else off = tid * 16;
+  constexpr bool READ = MODE == 0 || MODE == 3 || MODE == 5 || MODE == 6;
   u32x4 v = {(unsigned)tid, (unsigned)tid + 1, (unsigned)tid + 2, (unsigned)tid + 3};
   float acc = 0.f;
   const long long t0 = __builtin_readcyclecounter();
@@ -33,7 +37,7 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, long long* cyc, int 
     // (inline asm: from C++ hipcc narrows a 16-byte LDS read of which two words are used to ds_read2_b32 -- what round 3's
     //  lds_pitch_bench.hip measured without noticing.)  Four instructions in flight per wave, 16 per CU: the LDS pipe is the limit.
     const unsigned addr = (unsigned)(size_t)(smem + off + (it & 4) * 6144);
-    if (MODE == 0 || MODE == 3) {
+    if (READ) {
       u32x4 x0, x1, x2, x3;
       asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:6144\n\tds_read_b128 %2, %4 offset:12288\n\t"
                    "ds_read_b128 %3, %4 offset:18432\n\ts_waitcnt lgkmcnt(0)"
@@ -73,6 +77,8 @@ int main() {
   run<2>("W48R", out, cyc, iters);
   run<3>("RL16", out, cyc, iters);
   run<4>("WL16", out, cyc, iters);
+  run<5>("R48x2", out, cyc, iters);
+  run<6>("R48x4", out, cyc, iters);
   hipDeviceSynchronize();
   printf("done\n");
   return 0;

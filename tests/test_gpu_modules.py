@@ -762,18 +762,18 @@ def test_side_stream_weight_gradients_equal_main_stream(hip):
         assert all(torch.equal(a, b) for a, b in zip(out["off"], out[mode])), mode
 
 
-@pytest.mark.parametrize("size", [32, 48])
-def test_deferred_weight_gradient_reduction_is_bit_identical(hip, size):
+@pytest.mark.parametrize("pair", [True, False])
+def test_deferred_weight_gradient_reduction_is_bit_identical(hip, pair):
     """functional.DeferredReduce (mi355_conv_wgrad_partial + ONE mi355_wgrad_reduce_multi launch per 16 layers at the end of a
     backward pass) against every weight-gradient launch followed by its own reduction: the same kernel bodies and summation
-    order per layer, so every parameter after four steps is bit-identical, eagerly and under hipGraph replay.  48^3 is not
-    a multiple of 32: the discriminator phase falls back to two calls, every discriminator weight receives two contributions
-    and the second one (accumulating) flushes the pending reductions first."""
+    order per layer, so every parameter after four steps is bit-identical, eagerly and under hipGraph replay.  pair = False: the
+    discriminator phase is two calls (as for extents that are not multiples of 32), every discriminator weight receives two
+    contributions and the second one (accumulating) flushes the pending reductions first."""
     import unet_bssfp_amd as M
     from unet_bssfp_amd import functional as Fn
     from unet_bssfp_amd.functional import DropoutState
     from unet_bssfp_amd.gan import GraphedTrainingStep, bSSFPToDWITensorModel, synthetic_batch
-    batch = synthetic_batch(2, size, seed=9, device=DEV)
+    batch = synthetic_batch(2, 32, seed=9, device=DEV)
     out = {}
     try:
         for mode in ("immediate", "deferred_eager", "deferred_graph"):
@@ -782,6 +782,7 @@ def test_deferred_weight_gradient_reduction_is_bit_identical(hip, size):
             torch.manual_seed(4)
             DropoutState.reset()
             model = bSSFPToDWITensorModel("bssfp", gen=M.Generator("bssfp", dropout=0.05).to(DEV), discr=M.Discriminator("bssfp").to(DEV)).train()
+            model.pair_discriminator_calls = pair
             if mode == "deferred_graph":
                 gs = GraphedTrainingStep(model, batch, warmup=2)
                 gs(); gs()

@@ -916,6 +916,63 @@ def test_generator_output_seam_equals_unpack_add_pack(hip, which):
     assert torch.equal(z.grad, ref)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("drop_p", [0.0, 0.05])
+def test_norm_backward_forms_the_maxpool_gradient_itself(hip, dtype, drop_p):
+    """Fn.LazyPool: MaxPool3d(2)'s backward (+ the skip connection's gradient) formed per row inside the producing norm + act
+    node's backward kernels from the window positions the forward max-pool recorded (mi355_maxpool2_fwd_idx,
+    mi355_normact_desc::pool_idx) -- bit-identical to the max-pool backward launch followed by the plain kernels: ops level
+    (with and without a skip gradient, ties and a skip gradient that is a channel slice of a wider buffer) and through autograd
+    (NormActFn -> SkipPoolFn.apply_to) against the eager graph; the recorded positions are torch's max_pool3d indices."""
+    from unet_bssfp_amd import functional as Fn, ops
+    g = torch.Generator().manual_seed(29)
+    n, c, sp = 2, 32, (8, 12, 32)
+    z = to_act(q(torch.randn(n, c, *sp, generator=g) * 1.5 + 0.3, dtype), dtype)
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).to(DEV), (torch.rand(c, generator=g) - 0.5).to(DEV)
+    rows = sp[0] * sp[1] * sp[2]
+    part, ppg = ops.channel_stats(z, n)
+    mean, rstd = ops.norm_finalize(part, ppg, n, c, rows, None, 1e-5, None, None, 0.1, n_real=0)
+    seed_t = Fn.DropoutState.base(DEV) if drop_p > 0 else None
+    a = ops.normact_fwd(z, n, mean, rstd, gamma, beta, 0.1, drop_p, 5, seed_t=seed_t)
+    a[:, :2, :2, :2, :] = 0.0                              # ties: the first maximum in scan order takes the gradient
+    y, idx = ops.maxpool2_fwd(a, want_idx=True)
+    assert torch.equal(y, ops.maxpool2_fwd(a))
+    # the recorded window position against torch's flat argmax index
+    a_nc = a.float().permute(0, 4, 1, 2, 3).cpu()
+    _, flat = F.max_pool3d(a_nc, 2, return_indices=True)
+    fd, fh, fw = flat // (sp[1] * sp[2]), (flat // sp[2]) % sp[1], flat % sp[2]
+    ref_idx = ((fd & 1) * 4 + (fh & 1) * 2 + (fw & 1)).permute(0, 2, 3, 4, 1).to(torch.uint8)
+    assert torch.equal(idx.cpu(), ref_idx)
+    dy = to_act(q(torch.randn(n, c, sp[0] // 2, sp[1] // 2, sp[2] // 2, generator=g), dtype), dtype)
+    wide = to_act(q(torch.randn(n, 2 * c, *sp, generator=g), dtype), dtype)
+    for add in (None, wide[..., c:]):
+        da = ops.maxpool2_bwd(a, y, dy, add)
+        e = ops.normact_bwd(z, da, n, mean, rstd, gamma, beta, 0.1, drop_p, 5, True, True, seed_t=seed_t)
+        i = ops.normact_bwd(z, add, n, mean, rstd, gamma, beta, 0.1, drop_p, 5, True, True, seed_t=seed_t, pool=(idx, dy))
+        torch.cuda.synchronize()
+        for t_e, t_i in zip(e, i):
+            assert torch.equal(t_e, t_i)
+    # through autograd
+    cfg = Fn.NormCfg("instance", c, slope=0.1, p=drop_p)
+    outs = []
+    try:
+        for lazy in (False, True):
+            Fn.LazyPool.enabled = lazy
+            Fn.DropoutState._salt = 0
+            zz = z.clone().requires_grad_(True)
+            gg, bb = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+            act = Fn.NormActFn.apply(zz, None, gg, bb, None, cfg, True, None, None, False, None, False, 1, None, None, None)
+            skip, pooled = Fn.SkipPoolFn.apply_to(act)
+            torch.autograd.backward([skip, pooled], [wide[..., c:], dy])
+            torch.cuda.synchronize()
+            outs.append((zz.grad, gg.grad, bb.grad))
+        assert not Fn.LazyPool._by_ptr
+    finally:
+        Fn.LazyPool.enabled = True
+    for t_e, t_i in zip(*outs):
+        assert torch.equal(t_e, t_i)
+
+
 @pytest.mark.parametrize("drop_p", [0.0, 0.05])
 def test_norm_backward_forms_the_final_convs_data_gradient_itself(hip, drop_p):
     """mi355_normact_bwd_reduce / _apply with gz / gw (Fn.LazyDx): the data gradient of the 1x1x1 convolution that consumed a

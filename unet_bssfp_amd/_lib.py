@@ -63,7 +63,8 @@ class NormActDesc(C.Structure):
                 ("s2d_a", _i32), ("s2d_da", _i32), ("sd", _i32), ("sh", _i32), ("sw", _i32), ("seed_ptr", _vp),
                 ("n_affine", _i32), ("q8", _vp), ("ld8", _i32), ("q_use", _vp), ("q_next", _vp),
                 ("gz", _vp), ("ldgz", _i32), ("gw", _vp), ("gw_ld", _i32), ("gk", _i32),
-                ("fy", _vp), ("ldfy", _i32), ("fcp", _i32), ("fbias", _vp), ("skip_a", _i32)]
+                ("fy", _vp), ("ldfy", _i32), ("fcp", _i32), ("fbias", _vp), ("skip_a", _i32),
+                ("pool_idx", _vp), ("pool_dy", _vp), ("ldpdy", _i32)]
 
 
 class NormSmallDesc(C.Structure):
@@ -112,6 +113,7 @@ _SIGNATURES = {
     "mi355_colsum_finalize_into": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp]),
     "mi355_colsum_finalize_from": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "mi355_maxpool2_fwd": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mi355_maxpool2_fwd_idx": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mi355_maxpool2_bwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mi355_maxpool2_bwd_add": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mi355_l1_blocks": (_i32, [_i64]),

@@ -218,6 +218,19 @@ __global__ __launch_bounds__(256, 1) void conv_lowg_kernel(const ConvArgs a) {
   constexpr int NWP = 9 * 64 * 2, NWI = (NWP + 255) / 256;                       // ... of a weight slot
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wl = smem + 2 * Cfg::HALO;
+  // piece -> (voxel or weight row, 16-byte half).  Round 3 took (p >> 1, p & 1): lanes 2 v and 2 v + 1 wrote the two halves of
+  // row v, so 16 consecutive lanes covered 8 rows x 32 of every 48 bytes -- 13 of the 16 bank groups, three of them twice: the
+  // ds_write_b128 took 16 cycles instead of 8 (tests/diag/lds_rw_bench.hip: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.50 for that
+  // write pattern, 0 for the kernel's reads: THIS was the 42 % of profiles/r03_pmc_conv_lowg.txt).  Now 16 consecutive lanes
+  // write the same half of 16 consecutive rows (row * 48: all 16 bank groups, the property of the fragment reads), the next
+  // 16 lanes the other half; a trailing group of fewer than 32 pieces keeps the plain order.
+#ifdef LOWG_DIAG_PLAIN_PIECES      // (timing A/B of round 3's order: tools/build_variants.sh plain="-DLOWG_DIAG_PLAIN_PIECES")
+  auto piece_row = [](int p, int) __attribute__((always_inline)) { return p >> 1; };
+  auto piece_half = [](int p, int) __attribute__((always_inline)) { return p & 1; };
+#else
+  auto piece_row = [](int p, int np) __attribute__((always_inline)) { return (p | 31) < np ? ((p & ~31) >> 1) + (p & 15) : p >> 1; };
+  auto piece_half = [](int p, int np) __attribute__((always_inline)) { return (p | 31) < np ? (p >> 4) & 1 : p & 1; };
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(256, 1) void conv_lowg_kernel(const ConvArgs a) {
   int gvox[NP];
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
-    const int p = min(tid + i * 256, NPIECE - 1), vox = p >> 1;          // (threads beyond the last piece duplicate it)
+    const int p = min(tid + i * 256, NPIECE - 1), vox = piece_row(p, NPIECE);   // (threads beyond the last piece duplicate it)
     const int hd = vox / (HW * HH), hh = (vox / HW) % HH, hw = vox % HW;
     const int gd = d0 + hd - a.pd, gh = h0 + hh - a.ph, gw = w0 + hw - a.pw;
     const bool ok = gd >= 0 && gd < a.di && gh >= 0 && gh < a.hi && gw >= 0 && gw < a.wi;
@@ -258,7 +271,7 @@ __global__ __launch_bounds__(256, 1) void conv_lowg_kernel(const ConvArgs a) {
     const long long ld_ = first_ ? a.ld0 : a.ld1;                                                                \
     const int cbase_ = first_ ? cb_ : cb_ - a.c0;                                                                \
     _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                             \
-      const int part_ = min(tid + i * 256, NPIECE - 1) & 1;                                                      \
+      const int part_ = piece_half(min(tid + i * 256, NPIECE - 1), NPIECE);                                      \
       if (gvox[i] >= 0) stage[i] = *reinterpret_cast<const uint4*>(src_ + ((long long)gvox[i] * ld_ + cbase_) * 2 + part_ * 16); \
       else stage[i] = make_uint4(0, 0, 0, 0);                                                                    \
     }                                                                                                            \
@@ -268,14 +281,14 @@ __global__ __launch_bounds__(256, 1) void conv_lowg_kernel(const ConvArgs a) {
     constexpr int n3_ = (NP + 2) / 3, lo_ = (K3) * n3_, hi_ = lo_ + n3_ < NP ? lo_ + n3_ : NP;                   \
     _Pragma("unroll") for (int i = lo_; i < hi_; ++i) {                                                          \
       const int p_ = min(tid + i * 256, NPIECE - 1);   /* (clamped threads rewrite the last piece with its own value) */ \
-      *reinterpret_cast<uint4*>(smem + (HB) * Cfg::HALO + (p_ >> 1) * VS + (p_ & 1) * 16) = stage[i];            \
+      *reinterpret_cast<uint4*>(smem + (HB) * Cfg::HALO + piece_row(p_, NPIECE) * VS + piece_half(p_, NPIECE) * 16) = stage[i]; \
     }                                                                                                            \
   }
 #define LOWG_STORE_CHUNK(HB)                                                                                     \
   {                                                                                                              \
     _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                             \
       const int p_ = tid + i * 256;                                                                              \
-      if (p_ < NPIECE) *reinterpret_cast<uint4*>(smem + (HB) * Cfg::HALO + (p_ >> 1) * VS + (p_ & 1) * 16) = stage[i]; \
+      if (p_ < NPIECE) *reinterpret_cast<uint4*>(smem + (HB) * Cfg::HALO + piece_row(p_, NPIECE) * VS + piece_half(p_, NPIECE) * 16) = stage[i]; \
     }                                                                                                            \
   }
   // weight slot of block (chunk c, kd): packed weights are [chunk][27 taps][coutp][16 channels].  TWO register sets: the
@@ -288,12 +301,13 @@ __global__ __launch_bounds__(256, 1) void conv_lowg_kernel(const ConvArgs a) {
   uint4 wa0, wa1, wa2, wa3, wa4, wb0, wb1, wb2, wb3, wb4;      // (named scalars: arrays of these ended up in scratch memory)
   auto w_src = [&](int b, int i) __attribute__((always_inline)) {
     const int c = c_begin_of + b / 3, kd = b - (b / 3) * 3;
-    const int p = min(tid + i * 256, NWP - 1);              // piece = (tap9, cout, half)
-    return reinterpret_cast<const uint4*>(a.wp + ((((long long)c * 27 + kd * 9 + (p >> 7)) * a.coutp + co_base + ((p >> 1) & 63)) * 32 + (p & 1) * 16));
+    const int p = min(tid + i * 256, NWP - 1);              // piece = (row = tap9 * 64 + cout, half)
+    const int row = piece_row(p, NWP);
+    return reinterpret_cast<const uint4*>(a.wp + ((((long long)c * 27 + kd * 9 + (row >> 6)) * a.coutp + co_base + (row & 63)) * 32 + piece_half(p, NWP) * 16));
   };
   auto w_dst = [&](int slot, int i) __attribute__((always_inline)) {
     const int p = min(tid + i * 256, NWP - 1);              // (the clamped threads rewrite piece NWP - 1 with its own value)
-    return reinterpret_cast<uint4*>(wl + slot * Cfg::WSLOT + (p >> 1) * Cfg::WROW + (p & 1) * 16);
+    return reinterpret_cast<uint4*>(wl + slot * Cfg::WSLOT + piece_row(p, NWP) * Cfg::WROW + piece_half(p, NWP) * 16);
   };
 #define LOWG_LOAD_W(W, B) { W##0 = *w_src(B, 0); W##1 = *w_src(B, 1); W##2 = *w_src(B, 2); W##3 = *w_src(B, 3); W##4 = *w_src(B, 4); }
 #define LOWG_STORE_W(W, SLOT) { *w_dst(SLOT, 0) = W##0; *w_dst(SLOT, 1) = W##1; *w_dst(SLOT, 2) = W##2; *w_dst(SLOT, 3) = W##3; *w_dst(SLOT, 4) = W##4; }
@@ -379,7 +393,7 @@ __global__ __launch_bounds__(256, 1) void conv_lowg_kernel(const ConvArgs a) {
     constexpr int n3_ = (NP + 2) / 3, i_ = kd * n3_ + (J);                                                       \
     if constexpr ((J) < n3_ && i_ < NP) {                                                                        \
       const int p_ = min(tid + i_ * 256, NPIECE - 1);   /* (clamped threads rewrite the last piece with its own value) */ \
-      *reinterpret_cast<uint4*>(smem + (1 - HB) * Cfg::HALO + (p_ >> 1) * VS + (p_ & 1) * 16) = stage[i_];       \
+      *reinterpret_cast<uint4*>(smem + (1 - HB) * Cfg::HALO + piece_row(p_, NPIECE) * VS + piece_half(p_, NPIECE) * 16) = stage[i_]; \
     }                                                                                                            \
   }
 #ifndef LOWG_DIAG_NO_MMA

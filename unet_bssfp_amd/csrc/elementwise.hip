@@ -456,6 +456,9 @@ struct NormActArgs {
   // forward, optional: the 1x1x1 convolution that consumes a, evaluated per row on the rounded bf16 values:
   // fy[row][k] = bf16(sum_ch a[row][ch] * bf16(gw[k][ch]) + fbias[k]), k < gk <= 8, channels gk .. fcp - 1 zero; skip_a: a itself is not stored
   char* fy; int ldfy; int fcp; const float* fbias; int skip_a;
+  // backward, optional: da is NOT materialised -- a was consumed by MaxPool3d(2) (and, optionally, a skip connection whose gradient
+  // is `da`): da[v][ch] = (pool_idx[o(v)][ch] == k(v) ? pool_dy[o(v)][ch] : 0) (+ da[v][ch]), rounded to T like the stored tensor
+  const uint8_t* pool_idx; const char* pool_dy; int ldpdy; int pd, ph, pw;
 };
 
 template <typename T, bool DROP>
@@ -647,6 +650,29 @@ __device__ __forceinline__ void implicit_da(const NormActArgs& q, long long grow
     }
   }
 }
+// implicit da (NormActArgs::pool_idx): the gradient MaxPool3d(2)'s backward would have written for global row `grow` (voxel
+// (n, d, h, w) of the full-resolution grid): the pooled gradient where this voxel was its window's (first) maximum -- the window
+// position recorded by maxpool_fwd_kernel -- plus the skip connection's gradient, rounded to T as maxpool_bwd_kernel stores it.
+template <typename T, int EPV>
+__device__ __forceinline__ void pooled_da(const NormActArgs& q, long long grow, int ch0, Vec16<T>& dv) {
+  const unsigned v = (unsigned)grow, W = (unsigned)q.pw, H = (unsigned)q.ph, D = (unsigned)q.pd;
+  const unsigned w_ = v % W, t1 = v / W, h_ = t1 % H, t2 = t1 / H, d_ = t2 % D, n_ = t2 / D;
+  const long long o = (((long long)n_ * (D >> 1) + (d_ >> 1)) * (H >> 1) + (h_ >> 1)) * (W >> 1) + (w_ >> 1);
+  const unsigned k = ((d_ & 1u) << 2) | ((h_ & 1u) << 1) | (w_ & 1u);
+  Vec16<T> gy;
+  gy.load(reinterpret_cast<const T*>(q.pool_dy) + o * q.ldpdy + ch0);
+  unsigned long long ib;
+  if constexpr (EPV == 8) ib = *reinterpret_cast<const unsigned long long*>(q.pool_idx + o * q.c + ch0);
+  else ib = *reinterpret_cast<const unsigned*>(q.pool_idx + o * q.c + ch0);
+  if (q.da) dv.load(reinterpret_cast<const T*>(q.da) + grow * q.ldda + ch0);
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) {
+    float t = ((unsigned)(ib >> (8 * j)) & 0xffu) == k ? gy.f[j] : 0.f;
+    if (q.da) t += dv.f[j];
+    if constexpr (sizeof(T) == 2) t = bf16_bits_to_f32(f32_to_bf16_bits(t));
+    dv.f[j] = t;
+  }
+}
 // g = da * dropout * lrelu'(pre);  xhat = (z - mean) * rstd  (xhat = z when there is no norm)
 template <bool DROP>
 __device__ __forceinline__ void bwd_elem(const NormActArgs& q, bool keep, float mu, float rs, float ga,
@@ -661,7 +687,8 @@ __device__ __forceinline__ void bwd_elem(const NormActArgs& q, bool keep, float 
   gout = pre > 0.f ? gv : gv * q.slope;
 }
 
-template <typename T, bool DROP, bool IMPL = false>
+// IMPL: 0 = da is a tensor, 1 = implicit 1x1x1 data gradient (gz), 2 = implicit max-pool backward (pool_idx)
+template <typename T, bool DROP, int IMPL = 0>
 __global__ __launch_bounds__(256) void normact_bwd_reduce_kernel(const NormActArgs q) {
   constexpr int EPV = Elem<T>::kPer16B;
   const int g = blockIdx.y, b = blockIdx.x;
@@ -675,13 +702,14 @@ __global__ __launch_bounds__(256) void normact_bwd_reduce_kernel(const NormActAr
   BwdConst<EPV> k;
   load_bwd_const<EPV>(q, g, (int)(threadIdx.x % (q.c / EPV)) * EPV, k);
   const unsigned long long seed = DROP ? eff_seed(q.seed, q.seed_ptr) : 0ull;
-  __shared__ uint4 wtab[IMPL ? kImplicitMaxC : 1];
-  if constexpr (IMPL) fill_implicit_w(q, wtab);
+  __shared__ uint4 wtab[IMPL == 1 ? kImplicitMaxC : 1];
+  if constexpr (IMPL == 1) fill_implicit_w(q, wtab);
   block_channel_sums<T>(q.c, r0, r1,
       [&](long long row, int ch0, float* s0, float* s1) {
         Vec16<T> zv, dv;
         zv.load(zb + row * q.ldz + ch0);
-        if constexpr (IMPL) implicit_da<T, EPV>(q, (long long)g * q.rows_per_group + row, wtab, ch0, dv);
+        if constexpr (IMPL == 1) implicit_da<T, EPV>(q, (long long)g * q.rows_per_group + row, wtab, ch0, dv);
+        else if constexpr (IMPL == 2) pooled_da<T, EPV>(q, (long long)g * q.rows_per_group + row, ch0, dv);
         else if (q.s2d_da.d) dv.load(reinterpret_cast<const T*>(q.da) + s2d_offset(q.s2d_da, (long long)g * q.rows_per_group + row, q.ldda) + ch0);
         else dv.load(db + row * q.ldda + ch0);
         unsigned keep = 0;
@@ -720,11 +748,11 @@ __global__ __launch_bounds__(1024) void normact_bwd_finalize_kernel(const float*
   }
 }
 
-template <typename T, bool DROP, bool IMPL = false>
-__global__ __launch_bounds__(256, IMPL ? 5 : 1) void normact_bwd_apply_kernel(const NormActArgs q) {   // (IMPL: 97 registers without the bound: 4 waves)
+template <typename T, bool DROP, int IMPL = 0>
+__global__ __launch_bounds__(256, IMPL == 1 ? 5 : 1) void normact_bwd_apply_kernel(const NormActArgs q) {   // (IMPL 1: 97 registers without the bound: 4 waves)
   constexpr int EPV = Elem<T>::kPer16B;
-  __shared__ uint4 wtab[IMPL ? kImplicitMaxC : 1];
-  if constexpr (IMPL) fill_implicit_w(q, wtab);          // (before the early return below: it ends with a barrier)
+  __shared__ uint4 wtab[IMPL == 1 ? kImplicitMaxC : 1];
+  if constexpr (IMPL == 1) fill_implicit_w(q, wtab);     // (before the early return below: it ends with a barrier)
   const int g = blockIdx.y;
   const int lpr = q.c / EPV, rpp = 256 / lpr;
   const int piece = threadIdx.x % lpr, rsub = threadIdx.x / lpr;
@@ -752,7 +780,8 @@ __global__ __launch_bounds__(256, IMPL ? 5 : 1) void normact_bwd_apply_kernel(co
   for (long long row = (long long)blockIdx.x * rpp + rsub; row < q.rows_per_group; row += stride) {
     Vec16<T> zv, dv;
     zv.load(zb + row * q.ldz + ch0);
-    if constexpr (IMPL) implicit_da<T, EPV>(q, (long long)g * q.rows_per_group + row, wtab, ch0, dv);
+    if constexpr (IMPL == 1) implicit_da<T, EPV>(q, (long long)g * q.rows_per_group + row, wtab, ch0, dv);
+    else if constexpr (IMPL == 2) pooled_da<T, EPV>(q, (long long)g * q.rows_per_group + row, ch0, dv);
     else if (q.s2d_da.d) dv.load(reinterpret_cast<const T*>(q.da) + s2d_offset(q.s2d_da, (long long)g * q.rows_per_group + row, q.ldda) + ch0);
     else dv.load(db + row * q.ldda + ch0);
     unsigned keep = 0;
@@ -1012,7 +1041,8 @@ __global__ __launch_bounds__(kSmallThreads) void normact_small_bwd_kernel(const 
 // ------------------------------------------------------------------ max-pool 2x2x2
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y,
-                                                           int ldy, int c, int d, int h, int w, long long total) {
+                                                           int ldy, int c, int d, int h, int w, long long total,
+                                                           uint8_t* __restrict__ widx) {
   constexpr int EPV = Elem<T>::kPer16B;
   const int lpr = c / EPV;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1025,6 +1055,11 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
   const int od = (int)(t % od_); const int n = (int)(t / od_);
   Vec16<T> m;
   bool firstv = true;
+  // window position (kd, kh, kw as 3 bits) of the element the BACKWARD kernel routes the gradient to: the first one in scan
+  // order that equals the maximum or is NaN (maxpool_bwd_kernel's `hit`), i.e. the first NaN if the window holds one, else the
+  // first occurrence of the maximum
+  unsigned long long where = 0;
+  unsigned nan_seen = 0;
 #pragma unroll
   for (int kd = 0; kd < 2; ++kd)
 #pragma unroll
@@ -1032,15 +1067,30 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
 #pragma unroll
       for (int kw = 0; kw < 2; ++kw) {
         const long long vox = (((long long)n * d + 2 * od + kd) * h + 2 * oh + kh) * w + 2 * ow + kw;
+        const unsigned long long kk = (unsigned long long)(kd * 4 + kh * 2 + kw);
         Vec16<T> v;
         v.load(x + vox * ldx + piece * EPV);
-        if (firstv) { m = v; firstv = false; }
-        else {
+        if (firstv) {
+          m = v; firstv = false;
 #pragma unroll
-          for (int j = 0; j < EPV; ++j) m.f[j] = (v.f[j] > m.f[j] || v.f[j] != v.f[j]) ? v.f[j] : m.f[j];
+          for (int j = 0; j < EPV; ++j) nan_seen |= (v.f[j] != v.f[j] ? 1u : 0u) << j;
+        } else {
+#pragma unroll
+          for (int j = 0; j < EPV; ++j) {
+            const bool isnan_ = v.f[j] != v.f[j];
+            const bool take = v.f[j] > m.f[j] || isnan_;
+            m.f[j] = take ? v.f[j] : m.f[j];
+            const bool mark = ((nan_seen >> j) & 1u) ? false : take;          // after the first NaN the position stays
+            where = mark ? ((where & ~(0xffull << (8 * j))) | (kk << (8 * j))) : where;
+            nan_seen |= (isnan_ ? 1u : 0u) << j;
+          }
         }
       }
   m.store(y + o * ldy + piece * EPV);
+  if (widx) {
+    if constexpr (EPV == 8) *reinterpret_cast<unsigned long long*>(widx + o * c + piece * EPV) = where;
+    else *reinterpret_cast<unsigned*>(widx + o * c + piece * EPV) = (unsigned)where;
+  }
 }
 
 // ODD: some extent is odd -- MaxPool3d(2) floors, the last plane / row / column belongs to no window: its gradient is zero
@@ -1698,6 +1748,13 @@ static int fill_normact(const mi355_normact_desc* d, NormActArgs* q, const char*
                 "%s: the fused 1x1x1 convolution needs bf16, 32 channels, gk <= 8 outputs in rows of fcp (8 .. 32) channels", who);
   MI355_REQUIRE(!d->skip_a || d->fy, "%s: skip_a without the fused convolution", who);
   q->fy = (char*)d->fy; q->ldfy = d->ldfy; q->fcp = d->fcp; q->fbias = d->fbias; q->skip_a = d->skip_a;
+  MI355_REQUIRE(!d->pool_idx || (d->pool_dy && !d->gz && !d->s2d_da && !d->s2d_a && d->sd >= 2 && d->sh >= 2 && d->sw >= 2 &&
+                                 !((d->sd | d->sh | d->sw) & 1) && d->ldpdy >= d->c && d->ldpdy % (d->dtype == MI355_DT_F32 ? 4 : 8) == 0 &&
+                                 ((long long)d->rows_per_group * d->groups) % ((long long)d->sd * d->sh * d->sw) == 0 &&
+                                 (long long)d->rows_per_group * d->groups < (1ll << 31) && (!d->da || d->ldda >= d->c)),
+                "%s: the implicit max-pool gradient needs pool_dy, even extents sd/sh/sw that divide the row count, and plain layouts", who);
+  q->pool_idx = (const uint8_t*)d->pool_idx; q->pool_dy = (const char*)d->pool_dy; q->ldpdy = d->ldpdy;
+  q->pd = d->sd; q->ph = d->sh; q->pw = d->sw;
   if (d->s2d_a || d->s2d_da) {
     MI355_REQUIRE((long long)d->sd * d->sh * d->sw * (d->groups == 1 ? 1 : 1) > 0 &&
                   ((long long)d->rows_per_group * d->groups) % ((long long)d->sd * d->sh * d->sw) == 0,
@@ -1746,14 +1803,22 @@ int mi355_normact_bwd_reduce(const mi355_normact_desc* d, void* stream) {
   NormActArgs q;
   int rc = fill_normact(d, &q, "normact_bwd_reduce");
   if (rc) return rc;
-  MI355_REQUIRE((d->gz || (d->da && d->ldda >= d->c)) && d->part && d->blocks_per_group > 0, "normact_bwd_reduce: bad argument");
+  MI355_REQUIRE((d->gz || d->pool_idx || (d->da && d->ldda >= d->c)) && d->part && d->blocks_per_group > 0, "normact_bwd_reduce: bad argument");
   dim3 grid(d->blocks_per_group, d->groups);
-  if (d->dtype == MI355_DT_F32) {
+  if (q.pool_idx) {
+    if (d->dtype == MI355_DT_F32) {
+      if (q.thr16) normact_bwd_reduce_kernel<float, true, 2><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+      else normact_bwd_reduce_kernel<float, false, 2><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+    } else {
+      if (q.thr16) normact_bwd_reduce_kernel<bf16_t, true, 2><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+      else normact_bwd_reduce_kernel<bf16_t, false, 2><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+    }
+  } else if (d->dtype == MI355_DT_F32) {
     if (q.thr16) normact_bwd_reduce_kernel<float, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
     else normact_bwd_reduce_kernel<float, false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
   } else if (q.gz) {
-    if (q.thr16) normact_bwd_reduce_kernel<bf16_t, true, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
-    else normact_bwd_reduce_kernel<bf16_t, false, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+    if (q.thr16) normact_bwd_reduce_kernel<bf16_t, true, 1><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+    else normact_bwd_reduce_kernel<bf16_t, false, 1><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
   } else {
     if (q.thr16) normact_bwd_reduce_kernel<bf16_t, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
     else normact_bwd_reduce_kernel<bf16_t, false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
@@ -1779,15 +1844,23 @@ int mi355_normact_bwd_apply(const mi355_normact_desc* d, void* stream) {
   NormActArgs q;
   int rc = fill_normact(d, &q, "normact_bwd_apply");
   if (rc) return rc;
-  MI355_REQUIRE((d->gz || (d->da && d->ldda >= d->c)) && d->dz && d->lddz >= d->c, "normact_bwd_apply: bad argument");
+  MI355_REQUIRE((d->gz || d->pool_idx || (d->da && d->ldda >= d->c)) && d->dz && d->lddz >= d->c, "normact_bwd_apply: bad argument");
   MI355_REQUIRE(!(d->mean && d->batch_stats) || d->sums, "normact_bwd_apply: sums required");
   dim3 grid(stream_blocks(d->rows_per_group, d->c, d->dtype), d->groups);
-  if (d->dtype == MI355_DT_F32) {
+  if (q.pool_idx) {
+    if (d->dtype == MI355_DT_F32) {
+      if (q.thr16) normact_bwd_apply_kernel<float, true, 2><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+      else normact_bwd_apply_kernel<float, false, 2><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+    } else {
+      if (q.thr16) normact_bwd_apply_kernel<bf16_t, true, 2><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+      else normact_bwd_apply_kernel<bf16_t, false, 2><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+    }
+  } else if (d->dtype == MI355_DT_F32) {
     if (q.thr16) normact_bwd_apply_kernel<float, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
     else normact_bwd_apply_kernel<float, false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
   } else if (q.gz) {
-    if (q.thr16) normact_bwd_apply_kernel<bf16_t, true, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
-    else normact_bwd_apply_kernel<bf16_t, false, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+    if (q.thr16) normact_bwd_apply_kernel<bf16_t, true, 1><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
+    else normact_bwd_apply_kernel<bf16_t, false, 1><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
   } else {
     if (q.thr16) normact_bwd_apply_kernel<bf16_t, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
     else normact_bwd_apply_kernel<bf16_t, false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
@@ -1841,6 +1914,11 @@ int mi355_normact_small_bwd(const mi355_normact_small_desc* d, void* stream) {
 
 int mi355_maxpool2_fwd(const void* x, int32_t ldx, void* y, int32_t ldy, int32_t n, int32_t c, int32_t d, int32_t h,
                        int32_t w, int32_t dtype, void* stream) {
+  return mi355_maxpool2_fwd_idx(x, ldx, y, ldy, nullptr, n, c, d, h, w, dtype, stream);
+}
+
+int mi355_maxpool2_fwd_idx(const void* x, int32_t ldx, void* y, int32_t ldy, uint8_t* idx, int32_t n, int32_t c, int32_t d,
+                           int32_t h, int32_t w, int32_t dtype, void* stream) {
   MI355_REQUIRE(x && y && n > 0, "maxpool_fwd: bad argument");
   MI355_REQUIRE(d >= 2 && h >= 2 && w >= 2, "maxpool: extents must be >= 2 (%d,%d,%d)", d, h, w);   // odd: floor, as MaxPool3d(2)
   int rc = check_rows(c, ldx, dtype, "maxpool_fwd");
@@ -1851,9 +1929,9 @@ int mi355_maxpool2_fwd(const void* x, int32_t ldx, void* y, int32_t ldy, int32_t
   const long long total = (long long)n * (d / 2) * (h / 2) * (w / 2) * (c / epv);
   dim3 grid((unsigned)((total + 255) / 256));
   if (dtype == MI355_DT_F32)
-    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (float*)y, ldy, c, d, h, w, total);
+    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (float*)y, ldy, c, d, h, w, total, idx);
   else
-    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, c, d, h, w, total);
+    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, c, d, h, w, total, idx);
   return mi355_check_launch("maxpool_fwd");
 }
 

@@ -378,6 +378,34 @@ class LazyDx:
         cls._by_ptr.clear()
 
 
+class LazyPool:
+    """The gradient of an encoder level's output -- MaxPool3d(2)'s backward plus the skip connection's gradient -- never
+    materialised (round 4): ``SkipPoolFn.backward`` returns an UNINITIALISED placeholder and registers (idx, d_pool, d_skip) under
+    it; the norm + act node that produced the level's output forms da per row inside its two backward kernels
+    (``ops.normact_bwd(pool=)``: the window positions recorded by the forward max-pool, one byte per pooled element).  That drops
+    the max-pool backward launch (at 128^3 x 32: 134 MB + 134 MB read, 134 MB written) and the two reads of its result; the
+    values are those the launch would have stored, bit for bit.  Only offered when the producer of the pooled tensor IS a
+    NormActFn node (checked on the autograd graph at forward time) and the extents are even; a node that cannot use it (the
+    small-tensor kernels, a space-to-depth output) materialises the gradient with the ordinary kernel."""
+    _by_ptr = {}
+    enabled = True              # bench.py --eager-pool-bwd turns it off (A/B)
+
+    @classmethod
+    def put(cls, placeholder, x, y, idx, d_pool, d_skip):
+        if len(cls._by_ptr) >= 8:
+            cls._by_ptr.clear()
+        cls._by_ptr[placeholder.data_ptr()] = (x, y, idx, d_pool, d_skip, tuple(placeholder.shape), placeholder)
+
+    @classmethod
+    def take(cls, t):
+        hit = cls._by_ptr.pop(t.data_ptr(), None)
+        return hit[:5] if hit is not None and hit[5] == tuple(t.shape) else None
+
+    @classmethod
+    def clear(cls):
+        cls._by_ptr.clear()
+
+
 class FusedFinal:
     """Output of a 1x1x1 convolution that the norm + act launch producing its input has already computed (ops.normact_fwd,
     final=): NormActFn.forward registers it under the activation, ConvFn.forward (lazy_dx=True: same single-consumer promise as
@@ -1193,6 +1221,7 @@ class DropoutState:
         StepMemo.clear()
         ColSumSide.clear()
         LazyDx.clear()
+        LazyPool.clear()
         FusedFinal.clear()
         Fp8Scales.advance(device)           # ... and the e4m3 scales gathered in the last step come into use
 
@@ -1312,6 +1341,13 @@ class NormActFn(Function):
             if ctx.small or ctx.s2d_out:
                 raise RuntimeError("LazyDx placeholder reached a norm node that cannot form the gradient itself")
             da = None
+        pool = None
+        lp = LazyPool.take(da) if da is not None else None     # (x, y, idx, d_pool, d_skip): MaxPool3d(2) + skip consumed a
+        if lp is not None:
+            if ctx.small or ctx.s2d_out:
+                da = ops.maxpool2_bwd(lp[0], lp[1], lp[3], lp[4])     # these kernels read a materialised gradient
+            else:
+                pool, da = (lp[2], lp[3]), lp[4]
         want_affine = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
         gamma_p, beta_p = ctx.affine_params
         sink = sink_of(gamma_p) if (ctx.needs_input_grad[2] and ctx.needs_input_grad[3] and mean is not None) else None
@@ -1341,13 +1377,13 @@ class NormActFn(Function):
             # both affine gradients straight into the parameters' .grad storage (gradsink.py)
             dz, _, _ = ops.normact_bwd(z, da, groups, mean, rstd, gp, bp, slope, p, seed, batch_stats, True,
                                        s2d=ctx.s2d_out, seed_t=ctx.seed_t, affine_into=(sink_grad(gamma_p), sink_grad(beta_p)),
-                                       accumulate=not sink.fresh(gamma_p), q8=q8, implicit=lazy)
+                                       accumulate=not sink.fresh(gamma_p), q8=q8, implicit=lazy, pool=pool)
             sink.written(gamma_p)
             sink.written(beta_p)
             return (done(dz),) + (None,) * 15
         dz, dgamma, dbeta = ops.normact_bwd(z, da, groups, mean, rstd, gp, bp, slope, p, seed, batch_stats,
                                             want_affine and mean is not None, s2d=ctx.s2d_out, seed_t=ctx.seed_t, q8=q8,
-                                            implicit=lazy)
+                                            implicit=lazy, pool=pool)
         dg = dgamma[:nch].contiguous() if (dgamma is not None and ctx.needs_input_grad[2]) else None
         dbt = dbeta[:nch].contiguous() if (dbeta is not None and ctx.needs_input_grad[3]) else None
         return (done(dz), None, dg, dbt) + (None,) * 12
@@ -1375,10 +1411,18 @@ class SkipPoolFn(Function):
     the max-pool backward kernel, instead of the engine launching a separate add over the full-resolution tensor."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, lazy=False):
+        """lazy: the caller found x's producer to be a NormActFn node (SkipPoolFn.apply_to): the backward may hand it a LazyPool
+        placeholder instead of the materialised gradient."""
         x = ops.as_act(x)
-        y = ops.maxpool2_fwd(x)
-        ctx.save_for_backward(x, y)
+        n, d, h, w, c = x.shape
+        ctx.lazy = bool(lazy and LazyPool.enabled and d % 2 == 0 and h % 2 == 0 and w % 2 == 0)
+        if ctx.lazy:
+            y, idx = ops.maxpool2_fwd(x, want_idx=True)
+            ctx.save_for_backward(x, y, idx)
+        else:
+            y = ops.maxpool2_fwd(x)
+            ctx.save_for_backward(x, y)
         ctx.set_materialize_grads(False)
         return x.view_as(x), y
 
@@ -1386,12 +1430,24 @@ class SkipPoolFn(Function):
     @once_differentiable
     def backward(ctx, d_skip, d_pool):
         if d_pool is None:
-            return d_skip
-        x, y = ctx.saved_tensors
+            return d_skip, None
+        x, y = ctx.saved_tensors[:2]
         add = None
         if d_skip is not None:
             add = d_skip if d_skip.stride(4) == 1 and d_skip.dtype == x.dtype else ops.as_act(d_skip)
-        return ops.maxpool2_bwd(x, y, ops.as_act(d_pool), add)
+        if ctx.lazy:
+            ph = torch.empty(x.shape, dtype=x.dtype, device=x.device)      # placeholder: never written, never read (LazyPool)
+            LazyPool.put(ph, x, y, ctx.saved_tensors[2], ops.as_act(d_pool), add)
+            return ph, None
+        return ops.maxpool2_bwd(x, y, ops.as_act(d_pool), add), None
+
+    @classmethod
+    def apply_to(cls, x):
+        """(skip, pooled) of an encoder level's output; offers the lazy gradient when x comes straight out of a norm + act node.
+        The caller promises that x has no other consumer (BasicUNet.forward: a level's output goes to forward_skip only) -- autograd
+        would otherwise add the uninitialised placeholder to the other consumer's gradient."""
+        fnode = x.grad_fn
+        return cls.apply(x, fnode is not None and type(fnode).__name__ == "NormActFnBackward")
 
 
 class L1LossFn(Function):

@@ -419,7 +419,7 @@ class Down(_Mi355Module):
 
     def forward_skip(self, x):
         """-> (x for the skip connection, this level's output): both uses of x leave one autograd node"""
-        skip, pooled = Fn.SkipPoolFn.apply(x)
+        skip, pooled = Fn.SkipPoolFn.apply_to(x)
         return skip, self.convs.forward_act(pooled)
 
 

@@ -647,13 +647,15 @@ def normact_fwd(z, groups, mean, rstd, gamma, beta, slope, drop_p=0.0, seed=0, o
 
 
 def normact_bwd(z, da, groups, mean, rstd, gamma, beta, slope, drop_p, seed, batch_stats, want_affine_grads,
-                s2d=False, seed_t=None, affine_into=None, accumulate=False, q8=None, implicit=None):
+                s2d=False, seed_t=None, affine_into=None, accumulate=False, q8=None, implicit=None, pool=None):
     """Returns (dz, dgamma, dbeta).  dgamma/dbeta are f32 [C] (None if there is no norm).
     s2d=True: `da` is a gradient in space-to-depth layout (the forward wrote S(a)).
     affine_into=(dgamma, dbeta): write (accumulate=True: add) the affine gradients into these caller-owned f32
     vectors of the real channel count instead of returning new ones (then None, None are returned for them).
     implicit=(gz, gw): `da` is not materialised (pass None): it is the data gradient of the 1x1x1 convolution that consumed a,
-    da = bf16(gz[..., :k] @ gw) with gz the NDHWC gradient of that convolution's output and gw its f32 weights (k, cin[,1,1,1])."""
+    da = bf16(gz[..., :k] @ gw) with gz the NDHWC gradient of that convolution's output and gw its f32 weights (k, cin[,1,1,1]).
+    pool=(idx, dy): `da` is the gradient of a's skip-connection use only (or None): the activation was also consumed by MaxPool3d(2)
+    (idx from maxpool2_fwd(want_idx=True), dy the pooled tensor's gradient) and the kernels form maxpool2_bwd(..., add=da) per row."""
     require_cuda(z, da)
     lib = _lib.load()
     n, dd, h, w, c = z.shape
@@ -669,6 +671,16 @@ def normact_bwd(z, da, groups, mean, rstd, gamma, beta, slope, drop_p, seed, bat
         assert gw2.shape[0] <= 8 and gw2.shape[0] <= gz.shape[4] and gw2.shape[1] <= c
         d.gz, d.ldgz, d.gw, d.gw_ld, d.gk = gz.data_ptr(), act_ld(gz), gw2.data_ptr(), gw2.shape[1], gw2.shape[0]
         keep_implicit = (gz, gw2)
+    elif pool is not None:
+        pidx, pdy = pool
+        require_cuda(pidx, pdy)
+        assert not s2d and pidx.dtype == torch.uint8 and pidx.is_contiguous() and pdy.dtype == z.dtype
+        assert tuple(pidx.shape) == (n, dd // 2, h // 2, w // 2, c) == tuple(pdy.shape) and dd % 2 == 0 and h % 2 == 0 and w % 2 == 0
+        d.pool_idx, d.pool_dy, d.ldpdy = pidx.data_ptr(), pdy.data_ptr(), act_ld(pdy)
+        d.sd, d.sh, d.sw = dd, h, w
+        if da is not None:
+            assert tuple(da.shape) == tuple(z.shape) and da.dtype == z.dtype
+            d.da, d.ldda = da.data_ptr(), act_ld(da)
     else:
         d.da, d.ldda = da.data_ptr(), act_ld(da)
     dz = torch.empty(z.shape, dtype=z.dtype, device=z.device)
@@ -785,13 +797,20 @@ def normact_small_bwd(z, da, groups, mean, rstd, gamma, beta, slope, drop_p, see
 
 
 # ------------------------------------------------------------------------------ pooling
-def maxpool2_fwd(x: torch.Tensor) -> torch.Tensor:
+def maxpool2_fwd(x: torch.Tensor, want_idx: bool = False):
+    """y = MaxPool3d(2)(x); want_idx: -> (y, idx) with idx (uint8, y's shape) the window position 4 kd + 2 kh + kw the backward
+    pass routes each pooled element's gradient to (normact_bwd's pool= reads it instead of a max-pool backward launch)."""
     require_cuda(x)
     n, d, h, w, c = x.shape
     y = torch.empty((n, d // 2, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
-    _lib.check(_lib.load().mi355_maxpool2_fwd(x.data_ptr(), act_ld(x), y.data_ptr(), act_ld(y), n, c, d, h, w,
-                                              _DT[x.dtype], _stream()), "maxpool2_fwd")
-    return y
+    if not want_idx:
+        _lib.check(_lib.load().mi355_maxpool2_fwd(x.data_ptr(), act_ld(x), y.data_ptr(), act_ld(y), n, c, d, h, w,
+                                                  _DT[x.dtype], _stream()), "maxpool2_fwd")
+        return y
+    idx = torch.empty(y.shape, dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.load().mi355_maxpool2_fwd_idx(x.data_ptr(), act_ld(x), y.data_ptr(), act_ld(y), idx.data_ptr(), n, c, d, h, w,
+                                                  _DT[x.dtype], _stream()), "maxpool2_fwd_idx")
+    return y, idx
 
 
 def maxpool2_bwd(x, y, dy, add=None) -> torch.Tensor:
