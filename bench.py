@@ -88,6 +88,7 @@ def parse():
     ap.add_argument("--separate-colsum", action="store_true", help="developer A/B: transposed-conv bias gradients by a separate pass over the gradient instead of the producing launch's statistics; reported")
     ap.add_argument("--immediate-reduce", action="store_true", help="developer A/B: every weight-gradient launch followed by its own slab reduction instead of the batched reduction at the end of a backward pass; reported")
     ap.add_argument("--eager-pool-bwd", action="store_true", help="developer A/B: MaxPool3d's backward as its own launch instead of inside the producing norm node's backward kernels; reported")
+    ap.add_argument("--separate-pool", action="store_true", help="developer A/B: MaxPool3d's forward as its own launch instead of inside the producing norm + act launch; reported")
     ap.add_argument("--composed-losses", action="store_true", help="developer A/B: BCE / L1 loss heads as composed torch ops instead of the one-launch kernels; reported")
     ap.add_argument("--side-stream", action="store_true", help="developer A/B: weight gradients of the small layers on a second stream (measured slower); reported")
     ap.add_argument("--small-norm-grouped", type=int, default=None, help="developer A/B: the same limit for BatchNorm tensors whose statistic groups one workgroup walks in order (forward_pair)")
@@ -428,6 +429,10 @@ def main():
         from unet_bssfp_amd import functional as _Fn5
         _Fn5.LazyPool.enabled = False
         nondefault["eager_pool_bwd"] = True
+    if a.separate_pool:
+        from unet_bssfp_amd import functional as _Fn6
+        _Fn6.PoolSide.enabled = False
+        nondefault["separate_pool"] = True
     if a.immediate_reduce:
         from unet_bssfp_amd import functional as _Fn4
         _Fn4.DeferredReduce.allowed = False

@@ -321,6 +321,10 @@ typedef struct mi355_normact_desc {
    * Bit-identical to mi355_maxpool2_bwd(_add) followed by the plain kernels; saves that launch's 134-MB write and 3 x 134 MB of
    * reads per backward pass at 128^3 x 32. */
   const void* pool_idx; const void* pool_dy; int32_t ldpdy;
+  /* optional, forward: MaxPool3d(2) of a in the pass that writes it (the same Down blocks): pool_y[(n, d/2, h/2, w/2)][ch] (rows of
+   * ldpy elements) and pool_widx (bytes, as mi355_maxpool2_fwd_idx) on the sd x sh x sw grid (even extents; a group is one sample
+   * or the whole batch); plain layouts, no q8 / fy.  Bit-identical to mi355_normact_fwd + mi355_maxpool2_fwd_idx. */
+  void* pool_y; int32_t ldpy; uint8_t* pool_widx;
 } mi355_normact_desc;
 int mi355_normact_fwd(const mi355_normact_desc* d, void* stream);
 int mi355_normact_bwd_reduce(const mi355_normact_desc* d, void* stream);

@@ -934,6 +934,10 @@ def test_norm_backward_forms_the_maxpool_gradient_itself(hip, dtype, drop_p):
     mean, rstd = ops.norm_finalize(part, ppg, n, c, rows, None, 1e-5, None, None, 0.1, n_real=0)
     seed_t = Fn.DropoutState.base(DEV) if drop_p > 0 else None
     a = ops.normact_fwd(z, n, mean, rstd, gamma, beta, 0.1, drop_p, 5, seed_t=seed_t)
+    # the pool in the launch that writes a (ops.normact_fwd(pool=True), Fn.PoolSide): the same three tensors, bit for bit
+    a_f, y_f, idx_f = ops.normact_fwd(z, n, mean, rstd, gamma, beta, 0.1, drop_p, 5, seed_t=seed_t, pool=True)
+    y_s, idx_s = ops.maxpool2_fwd(a, want_idx=True)
+    assert torch.equal(a_f, a) and torch.equal(y_f, y_s) and torch.equal(idx_f, idx_s)
     a[:, :2, :2, :2, :] = 0.0                              # ties: the first maximum in scan order takes the gradient
     y, idx = ops.maxpool2_fwd(a, want_idx=True)
     assert torch.equal(y, ops.maxpool2_fwd(a))
@@ -957,18 +961,19 @@ def test_norm_backward_forms_the_maxpool_gradient_itself(hip, dtype, drop_p):
     outs = []
     try:
         for lazy in (False, True):
-            Fn.LazyPool.enabled = lazy
+            Fn.LazyPool.enabled = Fn.PoolSide.enabled = lazy
             Fn.DropoutState._salt = 0
             zz = z.clone().requires_grad_(True)
             gg, bb = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
-            act = Fn.NormActFn.apply(zz, None, gg, bb, None, cfg, True, None, None, False, None, False, 1, None, None, None)
+            act = Fn.NormActFn.apply(zz, None, gg, bb, None, cfg, True, None, None, False, None, False, 1, None, None, None, True)
+            assert bool(Fn.PoolSide._by_ptr) == lazy
             skip, pooled = Fn.SkipPoolFn.apply_to(act)
             torch.autograd.backward([skip, pooled], [wide[..., c:], dy])
             torch.cuda.synchronize()
-            outs.append((zz.grad, gg.grad, bb.grad))
-        assert not Fn.LazyPool._by_ptr
+            outs.append((zz.grad, gg.grad, bb.grad, pooled.detach().clone(), skip.detach().clone()))
+        assert not Fn.LazyPool._by_ptr and not Fn.PoolSide._by_ptr
     finally:
-        Fn.LazyPool.enabled = True
+        Fn.LazyPool.enabled = Fn.PoolSide.enabled = True
     for t_e, t_i in zip(*outs):
         assert torch.equal(t_e, t_i)
 

@@ -114,7 +114,9 @@ def bench_upcat(dtype, reps, only=None):
 def bench_deconv(dtype, reps, only=None):
     """transposed conv k2 s2 (forward = one 1x1x1 GEMM with 8*Cout columns, data gradient = k2 s2 gather)"""
     from unet_bssfp_amd.nn import ConvTranspose3d
-    for name, cin, cout, s in [("64->64 @64^3->128^3", 64, 64, 64), ("128->64 @32^3->64^3", 128, 64, 32), ("512->256 @8^3->16^3", 512, 256, 8)]:
+    for name, cin, cout, s in [("64->64 @64^3->128^3", 64, 64, 64), ("128->64 @32^3->64^3", 128, 64, 32), ("512->256 @8^3->16^3", 512, 256, 8),
+                               ("64->64 @32^3->64^3 (upcat_2)", 64, 64, 32), ("128->128 @16^3->32^3 (upcat_3)", 128, 128, 16),
+                               ("256->256 @8^3->16^3 (upcat_4)", 256, 256, 8)]:
         if only and only not in name:
             continue
         layer = ConvTranspose3d(cin, cout).to(DEV)

@@ -64,7 +64,8 @@ class NormActDesc(C.Structure):
                 ("n_affine", _i32), ("q8", _vp), ("ld8", _i32), ("q_use", _vp), ("q_next", _vp),
                 ("gz", _vp), ("ldgz", _i32), ("gw", _vp), ("gw_ld", _i32), ("gk", _i32),
                 ("fy", _vp), ("ldfy", _i32), ("fcp", _i32), ("fbias", _vp), ("skip_a", _i32),
-                ("pool_idx", _vp), ("pool_dy", _vp), ("ldpdy", _i32)]
+                ("pool_idx", _vp), ("pool_dy", _vp), ("ldpdy", _i32),
+                ("pool_y", _vp), ("ldpy", _i32), ("pool_widx", _vp)]
 
 
 class NormSmallDesc(C.Structure):

@@ -459,6 +459,9 @@ struct NormActArgs {
   // backward, optional: da is NOT materialised -- a was consumed by MaxPool3d(2) (and, optionally, a skip connection whose gradient
   // is `da`): da[v][ch] = (pool_idx[o(v)][ch] == k(v) ? pool_dy[o(v)][ch] : 0) (+ da[v][ch]), rounded to T like the stored tensor
   const uint8_t* pool_idx; const char* pool_dy; int ldpdy; int pd, ph, pw;
+  // forward, optional: MaxPool3d(2) of a in the pass that writes it: pool_y[o][ch] = max over the window, pool_widx = the window
+  // positions (as mi355_maxpool2_fwd_idx), extents pd x ph x pw (even)
+  char* pool_y; int ldpy; uint8_t* pool_widx;
 };
 
 template <typename T, bool DROP>
@@ -510,6 +513,86 @@ __global__ __launch_bounds__(256) void normact_fwd_kernel(const NormActArgs q) {
   }
   if constexpr (sizeof(T) == 2) {
     if (q.q8) amax_commit(m8, q.q_next);      // (c == 32: every lane of the wave is here)
+  }
+}
+
+// Norm + act TOGETHER WITH the MaxPool3d(2) that consumes the result (an encoder level of the U-Net: the activation goes to the
+// skip connection and to the pool, src/model.py:22-28 via MONAI's Down): thread = (pooled voxel, 16-byte piece) walks the eight
+// voxels of its window -- reads z, writes a, keeps the running maximum of the ROUNDED values (what maxpool_fwd_kernel would
+// read back) and its window position.  Saves the pool launch's read of a (134 MB at 128^3 x 32), in both generator forwards
+// of a training step.  blockIdx.y = sample.
+template <typename T, bool DROP>
+__global__ __launch_bounds__(256) void normact_pool_fwd_kernel(const NormActArgs q) {
+  constexpr int EPV = Elem<T>::kPer16B;
+  const int lpr = q.c / EPV, vpp = 256 / lpr;                     // pooled voxels per pass of the workgroup
+  const int piece = threadIdx.x % lpr, vsub = threadIdx.x / lpr;
+  if (vsub >= vpp) return;
+  const int ch0 = piece * EPV;
+  const int n_ = blockIdx.y;
+  const long long dhw = (long long)q.pd * q.ph * q.pw;
+  const int g = (int)(((long long)n_ * dhw) / q.rows_per_group);
+  const unsigned long long seed = DROP ? eff_seed(q.seed, q.seed_ptr) : 0ull;
+  float sc[EPV], sh[EPV];
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) {
+    const int ch = ch0 + j;
+    const float ga = q.gamma ? (ch < q.n_affine ? q.gamma[ch] : 0.f) : 1.f, be = (q.beta && ch < q.n_affine) ? q.beta[ch] : 0.f;
+    if (q.mean) {
+      const float rs = q.rstd[(long long)g * q.c + ch], mu = q.mean[(long long)g * q.c + ch];
+      sc[j] = ga * rs;
+      sh[j] = be - mu * ga * rs;
+    } else { sc[j] = ga; sh[j] = be; }
+  }
+  const int od_ = q.pd / 2, oh_ = q.ph / 2, ow_ = q.pw / 2;
+  const int pooled = od_ * oh_ * ow_;
+  const T* zb = reinterpret_cast<const T*>(q.z);
+  T* ab = reinterpret_cast<T*>(q.a);
+  for (int o = blockIdx.x * vpp + vsub; o < pooled; o += gridDim.x * vpp) {
+    const int ow = o % ow_, t = o / ow_, oh = t % oh_, od = t / oh_;
+    Vec16<T> m;
+    unsigned long long where = 0;
+    unsigned nan_seen = 0;
+#pragma unroll
+    for (int kd = 0; kd < 2; ++kd)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 2; ++kw) {
+          const long long vox = (((long long)n_ * q.pd + 2 * od + kd) * q.ph + 2 * oh + kh) * q.pw + 2 * ow + kw;
+          const unsigned long long kk = (unsigned long long)(kd * 4 + kh * 2 + kw);
+          Vec16<T> v;
+          v.load(zb + vox * q.ldz + ch0);
+          unsigned keep = 0;
+          if constexpr (DROP) keep = drop_keep_mask<EPV>(seed, (unsigned long long)vox * q.c + ch0, q.thr16);
+#pragma unroll
+          for (int j = 0; j < EPV; ++j) {
+            float t2 = v.f[j] * sc[j] + sh[j];
+            if constexpr (DROP) t2 = (keep >> j) & 1u ? t2 * q.drop_scale : 0.f;
+            t2 = t2 > 0.f ? t2 : t2 * q.slope;
+            if constexpr (sizeof(T) == 2) t2 = bf16_bits_to_f32(f32_to_bf16_bits(t2));      // the stored value
+            v.f[j] = t2;
+          }
+          v.store(ab + vox * q.lda + ch0);
+          if (kk == 0) {
+            m = v;
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) nan_seen |= (v.f[j] != v.f[j] ? 1u : 0u) << j;
+          } else {
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) {                       // (as maxpool_fwd_kernel)
+              const bool isnan_ = v.f[j] != v.f[j];
+              const bool take = v.f[j] > m.f[j] || isnan_;
+              m.f[j] = take ? v.f[j] : m.f[j];
+              const bool mark = ((nan_seen >> j) & 1u) ? false : take;
+              where = mark ? ((where & ~(0xffull << (8 * j))) | (kk << (8 * j))) : where;
+              nan_seen |= (isnan_ ? 1u : 0u) << j;
+            }
+          }
+        }
+    const long long orow = (long long)n_ * pooled + o;
+    m.store(reinterpret_cast<T*>(q.pool_y) + orow * q.ldpy + ch0);
+    if constexpr (EPV == 8) *reinterpret_cast<unsigned long long*>(q.pool_widx + orow * q.c + ch0) = where;
+    else *reinterpret_cast<unsigned*>(q.pool_widx + orow * q.c + ch0) = (unsigned)where;
   }
 }
 
@@ -1755,6 +1838,12 @@ static int fill_normact(const mi355_normact_desc* d, NormActArgs* q, const char*
                 "%s: the implicit max-pool gradient needs pool_dy, even extents sd/sh/sw that divide the row count, and plain layouts", who);
   q->pool_idx = (const uint8_t*)d->pool_idx; q->pool_dy = (const char*)d->pool_dy; q->ldpdy = d->ldpdy;
   q->pd = d->sd; q->ph = d->sh; q->pw = d->sw;
+  MI355_REQUIRE(!d->pool_y || (d->pool_widx && !d->pool_idx && !d->s2d_a && !d->s2d_da && !d->q8 && !d->fy && d->a && d->sd >= 2 &&
+                               d->sh >= 2 && d->sw >= 2 && !((d->sd | d->sh | d->sw) & 1) && d->ldpy >= d->c &&
+                               d->ldpy % (d->dtype == MI355_DT_F32 ? 4 : 8) == 0 &&
+                               d->rows_per_group % ((long long)d->sd * d->sh * d->sw) == 0),
+                "%s: the fused max-pool needs pool_widx, even extents sd/sh/sw that divide the row count, and plain layouts", who);
+  q->pool_y = (char*)d->pool_y; q->ldpy = d->ldpy; q->pool_widx = (uint8_t*)d->pool_widx;
   if (d->s2d_a || d->s2d_da) {
     MI355_REQUIRE((long long)d->sd * d->sh * d->sw * (d->groups == 1 ? 1 : 1) > 0 &&
                   ((long long)d->rows_per_group * d->groups) % ((long long)d->sd * d->sh * d->sw) == 0,
@@ -1782,6 +1871,22 @@ int mi355_normact_fwd(const mi355_normact_desc* d, void* stream) {
   if (rc) return rc;
   MI355_REQUIRE((d->a && d->lda >= d->c) || d->skip_a, "normact_fwd: bad output");
   dim3 grid(stream_blocks(d->rows_per_group, d->c, d->dtype), d->groups);
+  if (q.pool_y) {
+    const long long dhw = (long long)d->sd * d->sh * d->sw, samples = (long long)d->rows_per_group * d->groups / dhw;
+    const int epv = d->dtype == MI355_DT_F32 ? 4 : 8, vpp = 256 / (d->c / epv);
+    long long b = (dhw / 8 + vpp - 1) / vpp;                      // one window per thread and pass; up to ~2048 workgroups in all
+    const long long cap = std::max(1ll, 2048 / samples);
+    if (b > cap) b = cap;
+    const dim3 gridp((unsigned)b, (unsigned)samples);
+    if (d->dtype == MI355_DT_F32) {
+      if (q.thr16) normact_pool_fwd_kernel<float, true><<<gridp, dim3(256), 0, (hipStream_t)stream>>>(q);
+      else normact_pool_fwd_kernel<float, false><<<gridp, dim3(256), 0, (hipStream_t)stream>>>(q);
+    } else {
+      if (q.thr16) normact_pool_fwd_kernel<bf16_t, true><<<gridp, dim3(256), 0, (hipStream_t)stream>>>(q);
+      else normact_pool_fwd_kernel<bf16_t, false><<<gridp, dim3(256), 0, (hipStream_t)stream>>>(q);
+    }
+    return mi355_check_launch("normact_pool_fwd");
+  }
   if (d->dtype == MI355_DT_F32) {
     if (q.thr16) normact_fwd_kernel<float, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);
     else normact_fwd_kernel<float, false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(q);

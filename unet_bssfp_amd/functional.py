@@ -199,7 +199,8 @@ class DeferredReduce:
     the backward pass waits for: only the optimiser (and, under DDP, the bucket's all-reduce) reads a weight gradient.  Inside
     ``scope()`` (the harness's ``manual_backward``) the layers launch only their slab kernel (``mi355_conv_wgrad_partial``) and
     the reductions of up to ``max_jobs`` layers run as ONE launch (``mi355_wgrad_reduce_multi``): when that many are pending,
-    when a layer contributes a second time in the pass, and when the scope ends.  ``GradBuckets.written`` is called at
+    when a layer contributes a second time in the pass, when the pending ones would complete an eagerly exchanged DDP bucket
+    (its all-reduce has to be enqueued while backward kernels are still to come), and when the scope ends.  ``GradBuckets.written`` is called at
     the flush, so a bucket is exchanged only after its reductions have been enqueued.  Same kernels bodies and summation
     order per layer as the immediate form: bit-identical gradients (``test_deferred_weight_gradient_reduction_is_bit_identical``).
     Outside a scope (op-level use, ``loss.backward()`` on a bare network) nothing is deferred."""
@@ -227,7 +228,7 @@ class DeferredReduce:
         cls._jobs.extend(jobs)
         cls._after.append((sink, param))
         cls._params.add(id(param))
-        if len(cls._jobs) + 2 > cls.max_jobs:       # (a layer adds at most two jobs)
+        if len(cls._jobs) + 2 > cls.max_jobs or sink.completes_with(cls._after):    # (a layer adds at most two jobs)
             cls.flush()
 
     @classmethod
@@ -296,6 +297,22 @@ class Fp8Scales:
                 for s in slots:
                     s.primed, s.touched = s.primed or s.touched, False
         Fp8Side.clear()
+
+    @classmethod
+    def primed_slots(cls, device) -> set:
+        """slots with a history when the next step starts (primed, or touched by the step before: ``advance`` primes those)"""
+        return {id(s) for _, slots, _ in cls._chunks.get(device, ()) for s in slots if s.primed or s.touched}
+
+    @classmethod
+    def check_capture(cls, device, primed_before: set):
+        """``primed`` / ``touched`` are HOST flags that a hipGraph capture bakes into the captured launches (in-step amax pass or
+        delayed scale; which slots ``advance`` rolls): a slot that was first used inside the capture -- created by it, or never
+        primed by an eager step before it -- would replay its first-step form for ever.  GraphedTrainingStep runs at
+        least two eager steps first; this is the check that they did prime everything the captured step touches."""
+        bad = sum(1 for _, slots, _ in cls._chunks.get(device, ()) for s in slots if s.touched and id(s) not in primed_before)
+        if bad:
+            raise RuntimeError(f"fp8 delayed scaling: {bad} operand slot(s) were used for the first time inside a hipGraph capture; "
+                               "run the step eagerly (at least twice) before capturing it")
 
     @classmethod
     def saturated_steps(cls, device=None) -> int:
@@ -400,6 +417,28 @@ class LazyPool:
     def take(cls, t):
         hit = cls._by_ptr.pop(t.data_ptr(), None)
         return hit[:5] if hit is not None and hit[5] == tuple(t.shape) else None
+
+    @classmethod
+    def clear(cls):
+        cls._by_ptr.clear()
+
+
+class PoolSide:
+    """MaxPool3d(2) of an activation that the norm + act launch producing it has already computed (ops.normact_fwd, pool=True):
+    NormActFn.forward registers (y, idx) under the activation, SkipPoolFn.forward takes them instead of launching."""
+    _by_ptr = {}
+    enabled = True              # bench.py --separate-pool turns it off (A/B)
+
+    @classmethod
+    def put(cls, a, y, idx):
+        if len(cls._by_ptr) >= 8:
+            cls._by_ptr.clear()
+        cls._by_ptr[a.data_ptr()] = (y, idx, tuple(a.shape), a)
+
+    @classmethod
+    def take(cls, a):
+        hit = cls._by_ptr.pop(a.data_ptr(), None)
+        return (hit[0], hit[1]) if hit is not None and hit[2] == tuple(a.shape) else None
 
     @classmethod
     def clear(cls):
@@ -1222,6 +1261,7 @@ class DropoutState:
         ColSumSide.clear()
         LazyDx.clear()
         LazyPool.clear()
+        PoolSide.clear()
         FusedFinal.clear()
         Fp8Scales.advance(device)           # ... and the e4m3 scales gathered in the last step come into use
 
@@ -1237,7 +1277,7 @@ class NormActFn(Function):
     @staticmethod
     def forward(ctx, z, part, gamma, beta, conv_bias, cfg: NormCfg, training, running_mean, running_var,
                 s2d_out: bool = False, batches_tracked=None, small: bool = False, bn_groups: int = 1,
-                emit8=None, emit8_bwd=None, final=None):
+                emit8=None, emit8_bwd=None, final=None, pool_after: bool = False):
         """bn_groups > 1: BatchNorm statistics per consecutive sample group (two forward calls of the discriminator stacked
         along the batch: each group is normalised with its own batch statistics, the running statistics receive the groups'
         momentum updates in order -- exactly what two separate calls do)."""
@@ -1321,6 +1361,11 @@ class NormActFn(Function):
             a = ops.normact_fwd(z, groups, mean, rstd, gp, bp, cfg.slope, p, seed, seed_t=seed_t,
                                 final=(fw.detach(), fb.detach() if fb is not None else None, y), skip_a=skip_a)
             FusedFinal.put(a, y, fw)
+        elif (pool_after and PoolSide.enabled and not s2d_out and emit8 is None and d % 2 == 0 and h % 2 == 0 and w % 2 == 0
+              and (rows // groups) % (d * h * w) == 0):
+            # the activation's only consumer is SkipPoolFn (nn.Down.forward_skip): its MaxPool3d(2) in this launch (PoolSide)
+            a, py, pidx = ops.normact_fwd(z, groups, mean, rstd, gp, bp, cfg.slope, p, seed, seed_t=seed_t, pool=True)
+            PoolSide.put(a, py, pidx)
         else:
             a = ops.normact_fwd(z, groups, mean, rstd, gp, bp, cfg.slope, p, seed, seed_t=seed_t)
         ctx.s2d_out = s2d_out
@@ -1360,7 +1405,7 @@ class NormActFn(Function):
                 Fp8Side.put(dz, q8[0])
             return dz
         if ctx.small:
-            none11 = (None,) * 15
+            none11 = (None,) * 16
             if sink is not None and sink_of(beta_p) is sink:
                 dz, _, _ = ops.normact_small_bwd(z, da, groups, mean, rstd, gp, bp, slope, p, seed, batch_stats, s2d=ctx.s2d_out,
                                                  seed_t=ctx.seed_t, affine_into=(sink_grad(gamma_p), sink_grad(beta_p)),
@@ -1372,7 +1417,7 @@ class NormActFn(Function):
                                                       s2d=ctx.s2d_out, seed_t=ctx.seed_t, want_affine=want_affine)
             dg = dgamma[:nch].contiguous() if (dgamma is not None and ctx.needs_input_grad[2]) else None
             dbt = dbeta[:nch].contiguous() if (dbeta is not None and ctx.needs_input_grad[3]) else None
-            return (dz, None, dg, dbt) + (None,) * 12
+            return (dz, None, dg, dbt) + (None,) * 13
         if sink is not None and sink_of(beta_p) is sink:
             # both affine gradients straight into the parameters' .grad storage (gradsink.py)
             dz, _, _ = ops.normact_bwd(z, da, groups, mean, rstd, gp, bp, slope, p, seed, batch_stats, True,
@@ -1380,13 +1425,13 @@ class NormActFn(Function):
                                        accumulate=not sink.fresh(gamma_p), q8=q8, implicit=lazy, pool=pool)
             sink.written(gamma_p)
             sink.written(beta_p)
-            return (done(dz),) + (None,) * 15
+            return (done(dz),) + (None,) * 16
         dz, dgamma, dbeta = ops.normact_bwd(z, da, groups, mean, rstd, gp, bp, slope, p, seed, batch_stats,
                                             want_affine and mean is not None, s2d=ctx.s2d_out, seed_t=ctx.seed_t, q8=q8,
                                             implicit=lazy, pool=pool)
         dg = dgamma[:nch].contiguous() if (dgamma is not None and ctx.needs_input_grad[2]) else None
         dbt = dbeta[:nch].contiguous() if (dbeta is not None and ctx.needs_input_grad[3]) else None
-        return (done(dz), None, dg, dbt) + (None,) * 12
+        return (done(dz), None, dg, dbt) + (None,) * 13
 
 
 # ====================================================================================== pool / loss
@@ -1417,7 +1462,11 @@ class SkipPoolFn(Function):
         x = ops.as_act(x)
         n, d, h, w, c = x.shape
         ctx.lazy = bool(lazy and LazyPool.enabled and d % 2 == 0 and h % 2 == 0 and w % 2 == 0)
-        if ctx.lazy:
+        side = PoolSide.take(x)                 # (y, idx) written by the launch that wrote x
+        if side is not None:
+            y, idx = side
+            ctx.save_for_backward(*((x, y, idx) if ctx.lazy else (x, y)))
+        elif ctx.lazy:
             y, idx = ops.maxpool2_fwd(x, want_idx=True)
             ctx.save_for_backward(x, y, idx)
         else:

@@ -525,6 +525,14 @@ class GraphedTrainingStep:
                     raise RuntimeError(f"fp8 delayed-scaling slots {bad} are in use but not primed at capture time")
 
     def _capture(self, batch, pool, logs):
+        from .functional import Fp8Scales
+        dev = next(self.model.gen.parameters()).device
+        primed = Fp8Scales.primed_slots(dev)
+        graphs = self._capture_graphs(batch, pool, logs)
+        Fp8Scales.check_capture(dev, primed)
+        return graphs
+
+    def _capture_graphs(self, batch, pool, logs):
         model = self.model
         if not self.segmented:
             g = torch.cuda.CUDAGraph()

@@ -37,6 +37,13 @@ def _join_side_stream():
         fn.SideStream.join()
 
 
+def _flush_deferred_if_completing(sink):
+    import sys
+    fn = sys.modules.get(__package__ + ".functional")
+    if fn is not None and fn.DeferredReduce._after and sink.completes_with(fn.DeferredReduce._after):
+        fn.DeferredReduce.flush()
+
+
 def sink_grad(p: torch.Tensor) -> torch.Tensor:
     """``p.grad`` of a parameter owned by a GradBuckets object -- the permanent view into its bucket.  A caller that ran
     ``optimizer.zero_grad()`` (``set_to_none=True`` is torch's default) after the sinks were enabled has dropped that view:
@@ -112,6 +119,21 @@ class GradBuckets:
             self._pending[b] -= 1
             if self._pending[b] == 0 and self.exchange and self.auto_launch:
                 self.launch(b)
+            elif self.exchange and self.auto_launch:
+                _flush_deferred_if_completing(self)  # only deferred slab reductions may be missing from this bucket now
+
+    def completes_with(self, owed) -> bool:
+        """Would the ``written`` calls in ``owed`` [(sink, parameter), ...] complete a bucket that is exchanged eagerly?
+        (functional.DeferredReduce: such a bucket's reductions are flushed at once -- its all-reduce must be enqueued while
+        backward kernels are still to come, not at the end of the pass.)"""
+        if not (self.exchange and self.auto_launch):
+            return False
+        done = {}
+        for sink, p in owed:
+            if sink is self and self._count[id(p)] + 1 == self.uses:
+                b = self._where[id(p)]
+                done[b] = done.get(b, 0) + 1
+        return any(self._pending[b] == n and self._work[b] is None for b, n in done.items())
 
     # ------------------------------------------------------------------ per-phase control
     auto_launch = True      # eager steps: exchange a bucket as soon as its last gradient kernel is enqueued

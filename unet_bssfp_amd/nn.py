@@ -365,10 +365,13 @@ class Convolution(_Mi355Module):
         self.adn = _ADN(cout)
         self.cfg = Fn.NormCfg("instance", cout, eps=eps, slope=slope, p=float(dropout or 0.0))
 
-    def forward_act(self, x0, x1=None, feeds: Optional[Conv3d] = None, up_from=None, final: Optional[Conv3d] = None):
+    def forward_act(self, x0, x1=None, feeds: Optional[Conv3d] = None, up_from=None, final: Optional[Conv3d] = None,
+                    pool_after: bool = False):
         """feeds: the convolution that consumes the result (fp8 mode: the norm kernel writes its e4m3 operand as well);
         up_from = (x_low, deconv module, tables): the second source is ConvTranspose3d(x_low), which is NOT materialised
-        (Fn.UpCatConvFn: the up-branch as one transposed 4x4x4 convolution of the low-resolution tensor)"""
+        (Fn.UpCatConvFn: the up-branch as one transposed 4x4x4 convolution of the low-resolution tensor);
+        pool_after: the result's only consumer is Down.forward_skip (skip connection + MaxPool3d(2)): the norm + act launch writes
+        the pooled tensor as well (Fn.PoolSide)"""
         n, d, h, w = x0.shape[:4]
         cp = round_up(self.conv.out_channels, 16)
         # small levels (16^3, 8^3): the norm kernel computes the instance statistics itself, in one launch
@@ -396,7 +399,7 @@ class Convolution(_Mi355Module):
             # `final` is the 1x1x1 convolution that is this block's only consumer: evaluated by the norm + act launch itself
             fin = (final.weight, final.bias, not torch.is_grad_enabled())
         return Fn.NormActFn.apply(z, part if not small else None, self.adn.N.weight, self.adn.N.bias, shift, self.cfg,
-                                  self.training, None, None, False, None, small, 1, emit8, emit8_bwd, fin)
+                                  self.training, None, None, False, None, small, 1, emit8, emit8_bwd, fin, pool_after)
 
 
 class TwoConv(_Mi355Module):
@@ -405,8 +408,9 @@ class TwoConv(_Mi355Module):
         self.conv_0 = Convolution(cin, cout, dropout)
         self.conv_1 = Convolution(cout, cout, dropout)
 
-    def forward_act(self, x0, x1=None, up_from=None, final=None):
-        return self.conv_1.forward_act(self.conv_0.forward_act(x0, x1, feeds=self.conv_1.conv, up_from=up_from), final=final)
+    def forward_act(self, x0, x1=None, up_from=None, final=None, pool_after=False):
+        return self.conv_1.forward_act(self.conv_0.forward_act(x0, x1, feeds=self.conv_1.conv, up_from=up_from), final=final,
+                                       pool_after=pool_after)
 
 
 class Down(_Mi355Module):
@@ -417,10 +421,11 @@ class Down(_Mi355Module):
     def forward_act(self, x):
         return self.convs.forward_act(Fn.MaxPoolFn.apply(x))
 
-    def forward_skip(self, x):
-        """-> (x for the skip connection, this level's output): both uses of x leave one autograd node"""
+    def forward_skip(self, x, pool_after=False):
+        """-> (x for the skip connection, this level's output): both uses of x leave one autograd node.
+        pool_after: this level's output goes to the next level's forward_skip and nowhere else"""
         skip, pooled = Fn.SkipPoolFn.apply_to(x)
-        return skip, self.convs.forward_act(pooled)
+        return skip, self.convs.forward_act(pooled, pool_after=pool_after)
 
 
 class _UpSample(nn.Module):
@@ -551,16 +556,18 @@ class BasicUNet(_Mi355Module):
         if min(d, h, w) < 16 or (d >> 4) * (h >> 4) * (w >> 4) < 2:
             raise ValueError(f"four 2x poolings need extents >= 16, and InstanceNorm more than one element at the bottom "
                              f"level; got {tuple(x.shape[1:4])}")
-        x0 = self.conv_0.forward_act(x)
-        s0, x1 = self.down_1.forward_skip(x0)
-        s1, x2 = self.down_2.forward_skip(x1)
+        # (pool_after: a level's output goes to the next level's forward_skip and nowhere else -- its norm + act launch writes the
+        #  pooled tensor too, Fn.PoolSide, and its backward kernels form the pool's gradient themselves, Fn.LazyPool)
+        x0 = self.conv_0.forward_act(x, pool_after=True)
+        s0, x1 = self.down_1.forward_skip(x0, pool_after=True)
+        s1, x2 = self.down_2.forward_skip(x1, pool_after=True)
         if Fn.StageBoundary.active():
             # backward stage cut: everything from down_3 on | {down_2, down_1, conv_0, head}.  The skip tensors get a node of
             # their own: a gradient captured AT the two-output SkipPoolFn node would make autograd execute every path
             # into that node -- the pooled branch through down_1 / down_2 included -- already in the first stage.
             s0, s1 = s0.view_as(s0), s1.view_as(s1)
             Fn.StageBoundary.mark(x2, s1, s0)
-        s2, x3 = self.down_3.forward_skip(x2)
+        s2, x3 = self.down_3.forward_skip(x2, pool_after=True)
         s3, x4 = self.down_4.forward_skip(x3)
         u4 = self.upcat_4.forward_act(x4, s3)
         u3 = self.upcat_3.forward_act(u4, s2)

@@ -609,12 +609,14 @@ def _set_q8(d, q8):
 
 
 def normact_fwd(z, groups, mean, rstd, gamma, beta, slope, drop_p=0.0, seed=0, out=None, s2d=False, seed_t=None, q8=None,
-                final=None, skip_a=False):
+                final=None, skip_a=False, pool=False):
     """s2d=True: `out` is the space-to-depth tensor S(a) (s2d_shape) instead of a plain one; every slot of it is written.
     q8: also write the e4m3 copy of the result for the fp8 convolution that consumes it (see _set_q8).
     final=(w, bias, y): also evaluate the 1x1x1 convolution that consumes a -- y[..., k] = bf16(a @ bf16(w[k]) + bias[k]), w f32
     (k <= 8, cin[, 1, 1, 1]), y a bf16 NDHWC tensor on the same grid whose channels beyond k are zeroed; skip_a: a itself is not
-    written (the returned tensor is uninitialised)."""
+    written (the returned tensor is uninitialised).
+    pool=True: also MaxPool3d(2) of the result in the same pass -> (a, y, idx) as maxpool2_fwd(a, want_idx=True) (even extents,
+    plain layout, no q8 / final)."""
     require_cuda(z, mean, rstd, gamma, beta, out)
     if out is None:
         out = torch.empty(z.shape, dtype=z.dtype, device=z.device)
@@ -639,11 +641,19 @@ def normact_fwd(z, groups, mean, rstd, gamma, beta, slope, drop_p=0.0, seed=0, o
     if s2d:
         d.s2d_a = 1
         d.sd, d.sh, d.sw = z.shape[1:4]
+    py = pidx = None
+    if pool:
+        n, dd, h, w, c = z.shape
+        assert not s2d and q8 is None and final is None and dd % 2 == 0 and h % 2 == 0 and w % 2 == 0
+        py = torch.empty((n, dd // 2, h // 2, w // 2, c), dtype=z.dtype, device=z.device)
+        pidx = torch.empty(py.shape, dtype=torch.uint8, device=z.device)
+        d.pool_y, d.ldpy, d.pool_widx = py.data_ptr(), act_ld(py), pidx.data_ptr()
+        d.sd, d.sh, d.sw = dd, h, w
     after = _norm_probe("fwd", z, gamma)
     _lib.check(_lib.load().mi355_normact_fwd(C.byref(d), _stream()), "normact_fwd")
     if after is not None:
         after()
-    return out
+    return (out, py, pidx) if pool else out
 
 
 def normact_bwd(z, da, groups, mean, rstd, gamma, beta, slope, drop_p, seed, batch_stats, want_affine_grads,
