@@ -1,0 +1,4 @@
+#!/bin/bash
+tag=${1:-r4j}
+mkdir -p gpurun_out
+bash tools/ab_flags.sh 3 "--lib tools/_build/libmi355_unet_diag.so" "--lib tools/_build/libmi355_unet_P.so" 2>&1 | tee gpurun_out/${tag}_ab.txt

@@ -63,6 +63,30 @@ template <> struct Elem<fp8_t> {           // stores only (weight packing): the 
   static __device__ __forceinline__ void store(fp8_t* p, float v) { p->v = (uint8_t)(cvt_pk_fp8(v, 0.f, 0u, false) & 0xffu); }
 };
 
+// Cache-policy hints (round 4; interleaved step A/B over diagnostic builds, profiles/r04b_ab_cache_policy.txt): data that is read
+// for the last time in a pass, or written for a reader far away, takes the non-temporal policy so that it does not displace
+// what the NEXT kernels re-read from L2 / the 256 MB memory-side cache.  -DMI355_DIAG_NO_NT builds the round-3 policies.
+#ifndef MI355_DIAG_NO_NT
+#define NORM_NT_FWD 1       // normact_fwd / normact_pool_fwd: z is dead until the backward pass                      -0.02 ms per step
+#define NORM_NT_APPLY 1     // normact_bwd_apply: last reader of z and da                                            -0.08
+#define WGRAD_NT_SLABS 1    // weight-gradient slabs: ~800 MB per step written for the deferred reduction            -0.065
+#define ADAM_NT 1           // AdamW: gradients and moments are touched once per step                                -0.04
+#define WGRAD_NT_DENSE 1    // dense slab reduction: the slabs are read once (the generic form already did, round 2)  -0.04
+#endif
+// (measured without effect or worse, not kept: the LDS-DMA copies of the weight-gradient kernels' operands -- their last readers
+//  in the step -- with `nt` 9.921 against 9.918 ms; the f32 source of the input pack 9.913 against 9.918; the split-K slab loads of
+//  conv_ksplit_reduce_kernel 10.063 against 10.057.)
+// 16-byte non-temporal load (global_load_dwordx4 ... nt): bytes that are read for the last time in this pass
+__device__ __forceinline__ uint4 ld_nt_b128(const void* p) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  const u4 v = __builtin_nontemporal_load(reinterpret_cast<const u4*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st_nt_b128(void* p, const uint4 v) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  const u4 x = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(x, reinterpret_cast<u4*>(p));
+}
 // 16 bytes of T unpacked to floats (4 for f32, 8 for bf16)
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {
@@ -75,14 +99,19 @@ template <> struct Vec16<float> {
   __device__ __forceinline__ void from_bits(const uint4 v) {      // 16 bytes loaded earlier (kept packed while in flight)
     f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
   }
+  __device__ __forceinline__ void load_nt(const void* p) { from_bits(ld_nt_b128(p)); }   // last use of the bytes in this pass
   __device__ __forceinline__ void store(void* p) const {
     *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+  }
+  __device__ __forceinline__ void store_nt(void* p) const {          // no reader for a long time
+    st_nt_b128(p, make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])));
   }
 };
 template <> struct Vec16<bf16_t> {
   static constexpr int N = 8;
   float f[8];
   __device__ __forceinline__ void load(const void* p) { from_bits(*reinterpret_cast<const uint4*>(p)); }
+  __device__ __forceinline__ void load_nt(const void* p) { from_bits(ld_nt_b128(p)); }
   __device__ __forceinline__ void from_bits(const uint4 v) {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -97,6 +126,13 @@ template <> struct Vec16<bf16_t> {
     for (int i = 0; i < 4; ++i)
       w[i] = (uint32_t)f32_to_bf16_bits(f[2 * i]) | ((uint32_t)f32_to_bf16_bits(f[2 * i + 1]) << 16);
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  __device__ __forceinline__ void store_nt(void* p) const {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      w[i] = (uint32_t)f32_to_bf16_bits(f[2 * i]) | ((uint32_t)f32_to_bf16_bits(f[2 * i + 1]) << 16);
+    st_nt_b128(p, make_uint4(w[0], w[1], w[2], w[3]));
   }
 };
 

@@ -491,7 +491,11 @@ __global__ __launch_bounds__(256) void normact_fwd_kernel(const NormActArgs q) {
   float m8 = 0.f;
   for (long long row = (long long)blockIdx.x * rpp + rsub; row < q.rows_per_group; row += stride) {
     Vec16<T> v;
+#ifdef NORM_NT_FWD
+    v.load_nt(zb + row * q.ldz + ch0);
+#else
     v.load(zb + row * q.ldz + ch0);
+#endif
     const unsigned long long e0 = ((unsigned long long)g * q.rows_per_group + row) * q.c + ch0;
     unsigned keep = 0;
     if constexpr (DROP) keep = drop_keep_mask<EPV>(seed, e0, q.thr16);
@@ -561,7 +565,11 @@ __global__ __launch_bounds__(256) void normact_pool_fwd_kernel(const NormActArgs
           const long long vox = (((long long)n_ * q.pd + 2 * od + kd) * q.ph + 2 * oh + kh) * q.pw + 2 * ow + kw;
           const unsigned long long kk = (unsigned long long)(kd * 4 + kh * 2 + kw);
           Vec16<T> v;
+#ifdef NORM_NT_FWD
+          v.load_nt(zb + vox * q.ldz + ch0);
+#else
           v.load(zb + vox * q.ldz + ch0);
+#endif
           unsigned keep = 0;
           if constexpr (DROP) keep = drop_keep_mask<EPV>(seed, (unsigned long long)vox * q.c + ch0, q.thr16);
 #pragma unroll
@@ -572,7 +580,11 @@ __global__ __launch_bounds__(256) void normact_pool_fwd_kernel(const NormActArgs
             if constexpr (sizeof(T) == 2) t2 = bf16_bits_to_f32(f32_to_bf16_bits(t2));      // the stored value
             v.f[j] = t2;
           }
+#ifdef POOL_NT_A   // (a's next readers are the skip connection's consumer, a whole U-Net descent later, and the backward pass)
+          v.store_nt(ab + vox * q.lda + ch0);
+#else
           v.store(ab + vox * q.lda + ch0);
+#endif
           if (kk == 0) {
             m = v;
 #pragma unroll
@@ -862,11 +874,19 @@ __global__ __launch_bounds__(256, IMPL == 1 ? 5 : 1) void normact_bwd_apply_kern
   float m8 = 0.f;
   for (long long row = (long long)blockIdx.x * rpp + rsub; row < q.rows_per_group; row += stride) {
     Vec16<T> zv, dv;
+#ifdef NORM_NT_APPLY
+    zv.load_nt(zb + row * q.ldz + ch0);
+#else
     zv.load(zb + row * q.ldz + ch0);
+#endif
     if constexpr (IMPL == 1) implicit_da<T, EPV>(q, (long long)g * q.rows_per_group + row, wtab, ch0, dv);
     else if constexpr (IMPL == 2) pooled_da<T, EPV>(q, (long long)g * q.rows_per_group + row, ch0, dv);
     else if (q.s2d_da.d) dv.load(reinterpret_cast<const T*>(q.da) + s2d_offset(q.s2d_da, (long long)g * q.rows_per_group + row, q.ldda) + ch0);
+#ifdef NORM_NT_APPLY
+    else dv.load_nt(db + row * q.ldda + ch0);
+#else
     else dv.load(db + row * q.ldda + ch0);
+#endif
     unsigned keep = 0;
     if constexpr (DROP) keep = drop_keep_mask<EPV>(seed, ((unsigned long long)g * q.rows_per_group + row) * q.c + ch0, q.thr16);
 #pragma unroll
@@ -1357,6 +1377,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamChunk c, float lr,
   const float step_size = lr / bc1;
   const long long stride = (long long)gridDim.x * 256;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nel; i += stride) {
+#ifdef ADAM_NT      // (gradients and moments are touched once per step: keep them out of the caches the next kernels live off)
+    const float gi = __builtin_nontemporal_load(g + i);
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * __builtin_nontemporal_load(m + i) + (1.f - b1) * gi;
+    const float vi = b2 * __builtin_nontemporal_load(v + i) + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
+    pi -= step_size * (mi / denom);
+    p[i] = pi; __builtin_nontemporal_store(mi, m + i); __builtin_nontemporal_store(vi, v + i);
+#else
     const float gi = g[i];
     float pi = p[i] * (1.f - lr * wd);
     const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -1364,6 +1393,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamChunk c, float lr,
     const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
     pi -= step_size * (mi / denom);
     p[i] = pi; m[i] = mi; v[i] = vi;
+#endif
   }
 }
 

@@ -122,6 +122,14 @@ struct WreduceArgs {
 // but cost 0.3 ms per training step in the interleaved A/B -- twice the blocks, half the row length per block.)
 // slabs are written once and read once: non-temporal loads keep them from displacing the activations the next
 // kernels re-read (-0.04 ms per step, 3 of 3 interleaved rounds)
+// slab stores: written once, read once by a reduction that (round 4) runs at the end of the backward pass
+__device__ __forceinline__ void st_slab(float* p, float v) {
+#ifdef WGRAD_NT_SLABS
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
 __device__ __forceinline__ float4 ld_once(const float* p) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
@@ -220,7 +228,11 @@ __device__ __forceinline__ void wgrad_reduce_dense_body(const WreduceArgs& a, co
       for (int k0 = 0; k0 < a.nslabs; k0 += 4) {          // four slabs' loads in flight per pair, added in slab order
         float4 v[4];
 #pragma unroll
+#ifdef WGRAD_NT_DENSE
+        for (int j = 0; j < 4; ++j) v[j] = k0 + j < a.nslabs ? ld_once(base + (long long)(k0 + j) * per) : make_float4(0.f, 0.f, 0.f, 0.f);
+#else
         for (int j = 0; j < 4; ++j) v[j] = k0 + j < a.nslabs ? *reinterpret_cast<const float4*>(base + (long long)(k0 + j) * per) : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) { s[i].x += v[j].x; s[i].y += v[j].y; s[i].z += v[j].z; s[i].w += v[j].w; }
       }
@@ -459,7 +471,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradArgs a, i
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int row = ci_base + acc_row(j, h);
-        sl[((long long)tap * a.cinp + row) * a.coutp + co] = acc[i][j];
+        st_slab(&sl[((long long)tap * a.cinp + row) * a.coutp + co], acc[i][j]);
       }
     }
   }
@@ -728,7 +740,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_march_kernel(const WgradArgs a, 
         for (int j = 0; j < 16; ++j) {
           float v = acc[i][k][j] + parkA[(((half * 5 + i) * 3 + k) * 16 + j) * 64];
           if (i == 4) v = (v + parkB[(k * 16 + j) * 64]) + parkA[(((1 * 5 + 4) * 3 + k) * 16 + j) * 64];
-          sl[((long long)tap * a.cinp + ci_base + acc_row(j, h)) * a.coutp + co] = v;
+          st_slab(&sl[((long long)tap * a.cinp + ci_base + acc_row(j, h)) * a.coutp + co], v);
         }
       }
     }
@@ -813,7 +825,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_deconv_kernel(const WgradArgs a,
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int row = ci_base + acc_row(j, h);
-      sl[(long long)row * a.coutp + co] = acc[t][j];
+      st_slab(&sl[(long long)row * a.coutp + co], acc[t][j]);
     }
   }
 }
@@ -988,7 +1000,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_march2_kernel(const WgradArgs a,
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           const float v = acc[kh][kw][j] + park[((((kd * 2 + kh) * 2 + kw) * 16) + j) * 64];
-          sl[((long long)tap * a.cinp + ci_base + acc_row(j, h)) * a.coutp + co] = v;
+          st_slab(&sl[((long long)tap * a.cinp + ci_base + acc_row(j, h)) * a.coutp + co], v);
         }
       }
   }
@@ -1062,7 +1074,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_pw_kernel(const WgradArgs a, con
       float v = park[j * 64 + lane];
 #pragma unroll
       for (int w = 1; w < 4; ++w) v += park[(w * 16 + j) * 64 + lane];
-      sl[(long long)acc_row(j, h) * a.coutp + r] = v;
+      st_slab(&sl[(long long)acc_row(j, h) * a.coutp + r], v);
     }
   }
 }
