@@ -89,6 +89,7 @@ def parse():
     ap.add_argument("--immediate-reduce", action="store_true", help="developer A/B: every weight-gradient launch followed by its own slab reduction instead of the batched reduction at the end of a backward pass; reported")
     ap.add_argument("--eager-pool-bwd", action="store_true", help="developer A/B: MaxPool3d's backward as its own launch instead of inside the producing norm node's backward kernels; reported")
     ap.add_argument("--separate-pool", action="store_true", help="developer A/B: MaxPool3d's forward as its own launch instead of inside the producing norm + act launch; reported")
+    ap.add_argument("--wgrad-first", action="store_true", help="developer A/B: a convolution's backward launches its weight gradient before its data gradient; reported")
     ap.add_argument("--composed-losses", action="store_true", help="developer A/B: BCE / L1 loss heads as composed torch ops instead of the one-launch kernels; reported")
     ap.add_argument("--side-stream", action="store_true", help="developer A/B: weight gradients of the small layers on a second stream (measured slower); reported")
     ap.add_argument("--small-norm-grouped", type=int, default=None, help="developer A/B: the same limit for BatchNorm tensors whose statistic groups one workgroup walks in order (forward_pair)")
@@ -433,6 +434,10 @@ def main():
         from unet_bssfp_amd import functional as _Fn6
         _Fn6.PoolSide.enabled = False
         nondefault["separate_pool"] = True
+    if a.wgrad_first:
+        from unet_bssfp_amd import functional as _Fn7
+        _Fn7.ConvFn.wgrad_first = True
+        nondefault["wgrad_first"] = True
     if a.immediate_reduce:
         from unet_bssfp_amd import functional as _Fn4
         _Fn4.DeferredReduce.allowed = False

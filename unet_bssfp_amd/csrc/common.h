@@ -75,17 +75,14 @@ template <> struct Elem<fp8_t> {           // stores only (weight packing): the 
 #endif
 // (measured without effect or worse, not kept: the LDS-DMA copies of the weight-gradient kernels' operands -- their last readers
 //  in the step -- with `nt` 9.921 against 9.918 ms; the f32 source of the input pack 9.913 against 9.918; the split-K slab loads of
-//  conv_ksplit_reduce_kernel 10.063 against 10.057.)
+//  conv_ksplit_reduce_kernel 10.063 against 10.057; non-temporal STORES of activations whose next reader is far away -- the skip tensor
+//  written by normact_pool_fwd 10.025 against 10.013, the activation in front of the fused final convolution 9.869 against 9.886 --
+//  and z streamed in normact_bwd_reduce so that da stays cached for the apply pass 9.889 against 9.886: all within noise.)
 // 16-byte non-temporal load (global_load_dwordx4 ... nt): bytes that are read for the last time in this pass
 __device__ __forceinline__ uint4 ld_nt_b128(const void* p) {
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
   const u4 v = __builtin_nontemporal_load(reinterpret_cast<const u4*>(p));
   return make_uint4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ void st_nt_b128(void* p, const uint4 v) {
-  typedef unsigned u4 __attribute__((ext_vector_type(4)));
-  const u4 x = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(x, reinterpret_cast<u4*>(p));
 }
 // 16 bytes of T unpacked to floats (4 for f32, 8 for bf16)
 template <typename T> struct Vec16;
@@ -103,9 +100,7 @@ template <> struct Vec16<float> {
   __device__ __forceinline__ void store(void* p) const {
     *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
   }
-  __device__ __forceinline__ void store_nt(void* p) const {          // no reader for a long time
-    st_nt_b128(p, make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])));
-  }
+
 };
 template <> struct Vec16<bf16_t> {
   static constexpr int N = 8;
@@ -126,13 +121,6 @@ template <> struct Vec16<bf16_t> {
     for (int i = 0; i < 4; ++i)
       w[i] = (uint32_t)f32_to_bf16_bits(f[2 * i]) | ((uint32_t)f32_to_bf16_bits(f[2 * i + 1]) << 16);
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
-  }
-  __device__ __forceinline__ void store_nt(void* p) const {
-    uint32_t w[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      w[i] = (uint32_t)f32_to_bf16_bits(f[2 * i]) | ((uint32_t)f32_to_bf16_bits(f[2 * i + 1]) << 16);
-    st_nt_b128(p, make_uint4(w[0], w[1], w[2], w[3]));
   }
 };
 

@@ -580,11 +580,7 @@ __global__ __launch_bounds__(256) void normact_pool_fwd_kernel(const NormActArgs
             if constexpr (sizeof(T) == 2) t2 = bf16_bits_to_f32(f32_to_bf16_bits(t2));      // the stored value
             v.f[j] = t2;
           }
-#ifdef POOL_NT_A   // (a's next readers are the skip connection's consumer, a whole U-Net descent later, and the backward pass)
-          v.store_nt(ab + vox * q.lda + ch0);
-#else
           v.store(ab + vox * q.lda + ch0);
-#endif
           if (kk == 0) {
             m = v;
 #pragma unroll

@@ -751,6 +751,8 @@ class ConvSpec:
 
 class ConvFn(Function):
     """z = conv(x0 | x1) + bias  (optionally with fused per-tile channel statistics)."""
+    wgrad_first = False         # backward: weight gradient before the data gradient (bench.py --wgrad-first).  Measured: 10.018 against
+                                # 10.007 ms per step in the default order (three interleaved rounds) -- no gain, off
 
     @staticmethod
     def forward(ctx, x0, x1, weight, bias, spec: ConvSpec, want_stats: bool, zero_bias_grad: bool = False,
@@ -855,7 +857,7 @@ class ConvFn(Function):
         if need_dx and ctx.lazy_dx:
             dx0 = ops.new_act(n, di, hi, wi, c0, dtype, dev)       # placeholder: never written, never read (LazyDx)
             LazyDx.put(dx0, dz, ctx.weight_param.detach())
-        elif need_dx:
+        def dgrad(weight=weight):
             dxc = ops.new_act(n, di, hi, wi, c0 + c1, dtype, dev)
             # the second source of a skip concatenation comes from a transposed convolution whose bias gradient is the
             # per-channel sum of this data gradient: let the launch that writes it emit the sums (fused statistics)
@@ -898,6 +900,13 @@ class ConvFn(Function):
             dx1 = dxc[..., c0:] if c1 else None
             if sums is not None:
                 ColSumSide.put(dx1, sums, c0)
+            return dx0, dx1
+
+        run_dgrad = need_dx and not ctx.lazy_dx
+        # (ConvFn.wgrad_first: both readers of dz -- it was just written by the norm backward -- back to back; measured, no gain)
+        if run_dgrad and not ConvFn.wgrad_first:
+            dx0, dx1 = dgrad()
+            run_dgrad = False
         side = SideStream.enabled and n * do_ * ho * wo <= SideStream.max_rows
         if ctx.needs_input_grad[2]:
             # gradient storage owned by the path (gradsink.GradBuckets): the kernel writes (or, for a second use of the
@@ -962,6 +971,8 @@ class ConvFn(Function):
                 ops.colsum_from_parts(carried[0], carried[1], db)
             else:
                 db = ops.colsum(dz)[: spec.cout].contiguous()
+        if run_dgrad:
+            dx0, dx1 = dgrad()
         return dx0, dx1, dw, db, None, None, None, None, None, None
 
 
