@@ -1,7 +1,4 @@
 #!/bin/bash
-tag=${1:-r04b}
+tag=${1:-r4n}
 mkdir -p gpurun_out
-timeout -k 10 1000 python -m pytest tests -m gpu -q -x > gpurun_out/${tag}_pytest.log 2>&1; rc=$?
-echo "pytest rc=$rc"; tail -3 gpurun_out/${tag}_pytest.log
-[ $rc -ne 0 ] && exit $rc
-bash tools/gpu_artifacts.sh $tag b
+bash tools/ab_flags.sh 3 "--lib tools/_build/libmi355_unet_diag.so" "--lib tools/_build/libmi355_unet_l64.so" "--lib tools/_build/libmi355_unet_l128.so" 2>&1 | tee gpurun_out/${tag}_ab.txt

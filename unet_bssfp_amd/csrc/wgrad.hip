@@ -11,6 +11,7 @@
 #include "common.h"
 #include <type_traits>
 #include <cstring>
+#include <vector>
 
 namespace {
 
@@ -324,6 +325,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_s2d_kernel(const WreduceArgs
 constexpr int kRedChunk = 16;
 enum { kRedGeneric = 0, kRedGenericNarrow, kRedDense27_8, kRedDense27_4, kRedDense27_2, kRedDense1_8, kRedDense1_4, kRedDense1_2, kRedS2d };
 struct WreduceMulti { WreduceArgs a[kRedChunk]; int kind[kRedChunk], gx[kRedChunk], first[kRedChunk + 1]; int n; };
+// The jobs of the generic form (the marching kernels' 64 - 256 slabs per layer: most of the bytes) in a kernel of their own: 56 registers
+// and 4 KB of LDS instead of the union's 166 / 32 KB -- 8 waves per SIMD instead of 3 to keep the slab reads in flight.
+#ifndef LIGHT_F4
+#define LIGHT_F4 32
+#endif
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_light_kernel(const WreduceMulti m) {
+  __shared__ float4 red[256];
+  const int b = blockIdx.x;
+  int j = 0;
+  while (j + 1 < m.n && b >= m.first[j + 1]) ++j;
+  wgrad_reduce_body<LIGHT_F4, 256 / LIGHT_F4>(m.a[j], b - m.first[j], reinterpret_cast<float*>(red));
+}
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const WreduceMulti m) {
   __shared__ float smem[kRedLdsFloats];
   const int b = blockIdx.x;
@@ -1369,24 +1382,37 @@ extern "C" int mi355_conv_wgrad_partial(const mi355_wgrad_desc* d, mi355_wreduce
 extern "C" int mi355_wgrad_reduce_multi(const mi355_wreduce_job* jobs, int32_t n, void* stream) {
   MI355_REQUIRE(n >= 0 && (n == 0 || jobs), "wgrad_reduce_multi: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  for (int j0 = 0; j0 < n; j0 += kRedChunk) {
-    WreduceMulti m;
-    m.n = std::min(kRedChunk, n - j0);
-    long long blocks = 0;
-    for (int j = 0; j < kRedChunk; ++j) {
-      RedJob job;
-      memcpy(&job, jobs + j0 + std::min(j, m.n - 1), sizeof(job));      // (unused entries repeat the last job; never selected)
-      MI355_REQUIRE(job.magic == kRedMagic && job.kind >= kRedGeneric && job.kind <= kRedS2d && job.gx > 0 && job.gy > 0,
-                    "wgrad_reduce_multi: job %d was not filled by mi355_conv_wgrad_partial", j0 + j);
-      m.a[j] = job.q; m.kind[j] = job.kind; m.gx[j] = job.gx;
-      m.first[j] = (int)blocks;
-      if (j < m.n) blocks += (long long)job.gx * job.gy;
+  std::vector<RedJob> light, heavy;
+  for (int j = 0; j < n; ++j) {
+    RedJob job;
+    memcpy(&job, jobs + j, sizeof(job));
+    MI355_REQUIRE(job.magic == kRedMagic && job.kind >= kRedGeneric && job.kind <= kRedS2d && job.gx > 0 && job.gy > 0,
+                  "wgrad_reduce_multi: job %d was not filled by mi355_conv_wgrad_partial", j);
+#ifdef WGRAD_DIAG_ONE_MULTI      // (timing A/B: every job in the union kernel, as the first version of this call)
+    heavy.push_back(job);
+#else
+    (job.kind == kRedGeneric ? light : heavy).push_back(job);
+#endif
+  }
+  for (int pass = 0; pass < 2; ++pass) {
+    const std::vector<RedJob>& v = pass == 0 ? light : heavy;
+    for (size_t j0 = 0; j0 < v.size(); j0 += kRedChunk) {
+      WreduceMulti m;
+      m.n = (int)std::min<size_t>(kRedChunk, v.size() - j0);
+      long long blocks = 0;
+      for (int j = 0; j < kRedChunk; ++j) {
+        const RedJob& job = v[j0 + std::min(j, m.n - 1)];                // (unused entries repeat the last job; never selected)
+        m.a[j] = job.q; m.kind[j] = job.kind; m.gx[j] = job.gx;
+        m.first[j] = (int)blocks;
+        if (j < m.n) blocks += pass == 0 ? (((long long)job.q.ntaps * job.q.cinp * job.q.coutp + LIGHT_F4 * 4 - 1) / (LIGHT_F4 * 4)) : (long long)job.gx * job.gy;
+      }
+      m.first[kRedChunk] = (int)blocks;
+      MI355_REQUIRE(blocks > 0 && blocks < (1ll << 31), "wgrad_reduce_multi: bad block count");
+      if (pass == 0) wgrad_reduce_multi_light_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(m);
+      else wgrad_reduce_multi_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(m);
+      const int rc = mi355_check_launch("wgrad_reduce_multi");
+      if (rc) return rc;
     }
-    m.first[kRedChunk] = (int)blocks;
-    MI355_REQUIRE(blocks > 0 && blocks < (1ll << 31), "wgrad_reduce_multi: bad block count");
-    wgrad_reduce_multi_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(m);
-    const int rc = mi355_check_launch("wgrad_reduce_multi");
-    if (rc) return rc;
   }
   return MI355_OK;
 }
