@@ -1,4 +1,7 @@
 #!/bin/bash
-tag=${1:-r4n}
+# final call of the session: soak (bf16, fp8) + the bench lines of the final sources
+tag=${1:-r04b}
 mkdir -p gpurun_out
-bash tools/ab_flags.sh 3 "--lib tools/_build/libmi355_unet_diag.so" "--lib tools/_build/libmi355_unet_l64.so" "--lib tools/_build/libmi355_unet_l128.so" 2>&1 | tee gpurun_out/${tag}_ab.txt
+( timeout -k 10 200 python tools/soak.py --dtype bf16 --steps 1500 --every 250; timeout -k 10 200 python tools/soak.py --dtype fp8 --steps 1500 --every 250 ) > gpurun_out/${tag}_soak.txt 2>&1
+echo "soak rc=$?"; tail -4 gpurun_out/${tag}_soak.txt
+bash tools/gpu_artifacts.sh $tag b
