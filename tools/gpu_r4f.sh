@@ -1,7 +1,10 @@
 #!/bin/bash
-# final call of the session: soak (bf16, fp8) + the bench lines of the final sources
-tag=${1:-r04b}
+tag=${1:-r4o}
 mkdir -p gpurun_out
-( timeout -k 10 200 python tools/soak.py --dtype bf16 --steps 1500 --every 250; timeout -k 10 200 python tools/soak.py --dtype fp8 --steps 1500 --every 250 ) > gpurun_out/${tag}_soak.txt 2>&1
-echo "soak rc=$?"; tail -4 gpurun_out/${tag}_soak.txt
-bash tools/gpu_artifacts.sh $tag b
+python bench.py --size 160 --dtype fp8 --steps 20 --warmup 5 --no-cpu-baseline --no-probe > /dev/null 2>&1
+for r in 0 1 2; do
+  for cfg in "--dtype bf16 --lib tools/_build/libmi355_unet_diag.so" "--dtype fp8 --lib tools/_build/libmi355_unet_diag.so" "--dtype fp8 --lib tools/_build/libmi355_unet_f8a.so"; do
+    v=$(python bench.py --size 160 --steps 60 --no-cpu-baseline --no-probe $cfg 2>/dev/null | python -c "import sys,json; print(round(json.loads([l for l in sys.stdin if l.startswith('{')][-1])['ms_per_step'],3))")
+    echo "round $r [$cfg] $v ms"
+  done
+done | tee gpurun_out/${tag}_ab.txt
