@@ -328,7 +328,13 @@ def test_normact_fwd_bwd(hip, dtype, kind, n, c, sp):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("kind,n,c,sp,s2d", [("instance", 2, 128, (4, 6, 8), False), ("batch", 1, 256, (8, 8, 8), False),
-                                             ("batch", 2, 64, (4, 4, 8), True), ("instance", 1, 512, (2, 2, 2), False)])
+                                             ("batch", 2, 64, (4, 4, 8), True), ("instance", 1, 512, (2, 2, 2), False),
+                                             # register-resident forms: 8 row slots per thread (full / predicated, two groups one
+                                             # after the other), an odd group count; the streaming forms behind them: more than
+                                             # 4096 rows per group, more than 16 groups
+                                             ("instance", 1, 128, (16, 16, 16), False), ("instance", 2, 64, (8, 12, 16), False),
+                                             ("instance", 3, 64, (4, 4, 4), False), ("batch", 1, 64, (16, 16, 32), False),
+                                             ("instance", 32, 64, (2, 2, 2), False)])
 def test_normact_small_tensor_kernels(hip, dtype, kind, n, c, sp, s2d):
     """mi355_normact_small_fwd / _bwd (one launch each way for tensors of up to 1 M elements: the workgroup computes the
     statistics itself) against torch, and against the three-launch path on the same input: activations, input gradient,
@@ -382,6 +388,51 @@ def test_normact_small_tensor_kernels(hip, dtype, kind, n, c, sp, s2d):
     # the two paths agree with each other at least as well as either agrees with torch
     close(sm[0], big[0], dtype, "a: small vs three-launch path")
     close_f32_sum(sm[2], big[2], "dgamma: small vs three-launch path")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind,n,c,sp,bn_groups", [("instance", 1, 128, (16, 16, 16), 1), ("instance", 2, 128, (8, 8, 8), 1),
+                                                   ("batch", 2, 64, (16, 16, 16), 2), ("batch", 2, 512, (4, 4, 4), 2),
+                                                   ("batch", 4, 64, (8, 8, 8), 2)])
+def test_normact_small_resident_forms_equal_the_three_launch_path_with_dropout(hip, dtype, kind, n, c, sp, bn_groups):
+    """The one-launch kernels keep their rows in registers (normact_small_res_*: S = 1 / 8 slots, one or two statistic groups
+    per chunk).  With dropout and with BatchNorm over two statistic groups (the stacked PatchGAN pair) they must reproduce
+    the three-launch path on the same input and the same seed: same mask (a is zero at the same elements), activations and
+    input gradient to rounding, affine gradients, running statistics after the two groups' updates in order."""
+    from unet_bssfp_amd import functional as Fn, ops
+    assert ops.norm_is_small(n, *sp, c, bn_groups)
+    g = torch.Generator().manual_seed(23)
+    z = q(torch.randn(n, c, *sp, generator=g) * 1.3 - 0.4, dtype)
+    ga = q(torch.rand(n, c, *sp, generator=g) - 0.5, dtype)
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.rand(c, generator=g) - 0.5
+    bn = kind == "batch"
+    outs = {}
+    for small in (True, False):
+        Fn.DropoutState._salt = 0                              # the same salt, hence the same mask, for both paths
+        cfg = Fn.NormCfg(kind, c, slope=0.2, p=0.0 if bn else 0.1)
+        zd = to_act(z, dtype).requires_grad_(True)
+        gd, bd = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+        rmd, rvd = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+        nbt = torch.zeros((), dtype=torch.long, device=DEV)
+        a = Fn.NormActFn.apply(zd, None, gd, bd, None, cfg, True, rmd if bn else None, rvd if bn else None, False,
+                               nbt if bn else None, small, bn_groups)
+        a.backward(to_act(ga, dtype))
+        outs[small] = (from_act(a.detach(), c), from_act(zd.grad, c), gd.grad.cpu(), bd.grad.cpu(), rmd.cpu(), rvd.cpu(), int(nbt))
+    sm, big = outs[True], outs[False]
+    if not bn:
+        assert torch.equal(sm[0] == 0, big[0] == 0)
+        assert 0.08 < (sm[0] == 0).float().mean().item() < 0.12
+    close(sm[0], big[0], dtype, "a")
+    if dtype == torch.float32:
+        torch.testing.assert_close(sm[1], big[1], rtol=1e-3, atol=1e-5)
+    else:
+        close(sm[1], big[1], dtype, "dz")
+    close_f32_sum(sm[2], big[2], "dgamma")
+    close_f32_sum(sm[3], big[3], "dbeta")
+    if bn:
+        torch.testing.assert_close(sm[4], big[4], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(sm[5], big[5], rtol=1e-4, atol=1e-6)
+        assert sm[6] == big[6] == bn_groups
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -1162,6 +1162,273 @@ __global__ __launch_bounds__(kSmallThreads) void normact_small_bwd_kernel(const 
   }
 }
 
+// Register-resident forms (round 4, third session).  The kernels above are chains of dependent L2 round trips: the forward
+// kernel reads its column three times (mean, variance, apply), the backward kernel twice in four dependent iterations, and
+// the statistic groups of a stacked PatchGAN pair are walked one after the other -- 14 - 31 us for 64 KB per workgroup.
+// Every eligible tensor is at most 16 rows per thread (<= 512 K elements of >= 64 channels over 512 threads), so the rows
+// of GC groups x S slots stay in registers as the packed 16-byte pieces: ONE load latency per launch for GC groups, the
+// passes after it are arithmetic.  Row -> thread assignment, accumulation order and the f64 block sums are those of the
+// kernels above (bit-identical results); the host picks S = 1 (<= 512 rows per group) or 8 (<= 4096) and GC = 2 for an even
+// number of groups.
+constexpr int kSmallResMaxGroups = 16;
+// Block sums of NV per-thread f32 partials, combined in f64 in a fixed order, through an LDS transpose: block_sum_vec's 6-step
+// f64 butterfly per value is 12 ds_bpermute + 8 ds_read_b64 per value and THREAD -- 320 LDS instructions per wave for 16
+// values, and the LDS pipe of one CU serves all 8 waves: that, not the loads, was most of these kernels' time (two groups per
+// chunk cost 8 us more than one).  Here every thread writes its partials ([value][thread]: conflict-free), TPV threads per
+// value add 512 / TPV of them each (strided by TPV: conflict-free) and finish with a log2(TPV)-step butterfly on ONE value;
+// ~4 LDS instructions per value and thread.  CH values at a time (part: CH x 512 floats of LDS).
+template <int NV, int CH>
+__device__ __forceinline__ void block_sum_lds(const float (&v)[NV], double (&t)[NV], float* part /* [CH][kSmallThreads] */,
+                                              double* total /* [CH] */) {
+  static_assert(NV % CH == 0, "chunk");
+  constexpr int TPV = (kSmallThreads / CH) < 64 ? (kSmallThreads / CH) : 64, CNT = kSmallThreads / TPV;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int c0 = 0; c0 < NV; c0 += CH) {
+    __syncthreads();                                       // part / total may still be read from the previous round
+#pragma unroll
+    for (int i = 0; i < CH; ++i) part[i * kSmallThreads + tid] = v[c0 + i];
+    __syncthreads();
+    if (tid < CH * TPV) {
+      const int val = tid / TPV, sg = tid % TPV;
+      double a = 0.0;
+#pragma unroll
+      for (int i = 0; i < CNT; ++i) a += (double)part[val * kSmallThreads + i * TPV + sg];
+#pragma unroll
+      for (int o = 1; o < TPV; o <<= 1) a += __shfl_xor(a, o, 64);
+      if (sg == 0) total[val] = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < CH; ++i) t[c0 + i] = total[i];
+  }
+}
+template <typename T, bool DROP, int S, int GC>
+__global__ __launch_bounds__(kSmallThreads) void normact_small_res_fwd_kernel(const NormSmallArgs p) {
+  constexpr int EPV = Elem<T>::kPer16B, NV = GC * EPV;
+  constexpr int CH = NV < 16 ? NV : 16;
+  __shared__ float part[CH * kSmallThreads];
+  __shared__ double total[CH];
+  const NormActArgs& q = p.q;
+  const int ch0 = blockIdx.x * EPV;
+  const unsigned long long seed = DROP ? eff_seed(q.seed, q.seed_ptr) : 0ull;
+  float ga[EPV], be[EPV];
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) {
+    const int ch = ch0 + j;
+    ga[j] = q.gamma ? (ch < q.n_affine ? q.gamma[ch] : 0.f) : 1.f;
+    be[j] = (q.beta && ch < q.n_affine) ? q.beta[ch] : 0.f;
+  }
+  if (p.batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) p.batches_tracked[0] += q.groups;
+  const double inv = 1.0 / (double)q.rows_per_group;
+  const int rows = (int)q.rows_per_group;
+  for (int g0 = 0; g0 < q.groups; g0 += GC) {
+    uint4 raw[GC][S];
+#pragma unroll
+    for (int c = 0; c < GC; ++c) {
+      const T* zb = reinterpret_cast<const T*>(q.z) + (long long)(g0 + c) * q.rows_per_group * q.ldz + ch0;
+#pragma unroll
+      for (int u = 0; u < S; ++u) {
+        const int row = threadIdx.x + u * kSmallThreads;
+        raw[c][u] = row < rows ? *reinterpret_cast<const uint4*>(zb + (long long)row * q.ldz) : make_uint4(0, 0, 0, 0);
+      }
+    }
+    float s[NV], mu[NV], rs[NV];
+    double t[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s[i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < GC; ++c)
+#pragma unroll
+      for (int u = 0; u < S; ++u)
+        if ((int)threadIdx.x + u * kSmallThreads < rows) {
+          Vec16<T> v; v.from_bits(raw[c][u]);
+#pragma unroll
+          for (int j = 0; j < EPV; ++j) s[c * EPV + j] += v.f[j];
+        }
+    block_sum_lds<NV, CH>(s, t, part, total);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { mu[i] = (float)(t[i] * inv); s[i] = 0.f; }
+#pragma unroll
+    for (int c = 0; c < GC; ++c)
+#pragma unroll
+      for (int u = 0; u < S; ++u)
+        if ((int)threadIdx.x + u * kSmallThreads < rows) {
+          Vec16<T> v; v.from_bits(raw[c][u]);
+#pragma unroll
+          for (int j = 0; j < EPV; ++j) { const float d = v.f[j] - mu[c * EPV + j]; s[c * EPV + j] += d * d; }
+        }
+    block_sum_lds<NV, CH>(s, t, part, total);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) rs[i] = (float)(1.0 / sqrt(t[i] * inv + (double)p.eps));
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int c = 0; c < GC; ++c) {                       // (groups in order: the running statistics are a recurrence)
+        const int g = g0 + c;
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+          const int ch = ch0 + j;
+          p.mean_out[(long long)g * q.c + ch] = mu[c * EPV + j];
+          p.rstd_out[(long long)g * q.c + ch] = rs[c * EPV + j];
+          if (p.running_mean && ch < p.n_real) {
+            const double var = t[c * EPV + j] * inv;
+            const double unb = q.rows_per_group > 1 ? var * (double)q.rows_per_group / (double)(q.rows_per_group - 1) : var;
+            p.running_mean[ch] = (float)((1.0 - p.momentum) * p.running_mean[ch] + p.momentum * (double)mu[c * EPV + j]);
+            p.running_var[ch] = (float)((1.0 - p.momentum) * p.running_var[ch] + p.momentum * unb);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < GC; ++c) {
+      const int g = g0 + c;
+      float sc[EPV], sh[EPV];
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) { sc[j] = ga[j] * rs[c * EPV + j]; sh[j] = be[j] - mu[c * EPV + j] * ga[j] * rs[c * EPV + j]; }
+      T* ab = reinterpret_cast<T*>(q.a) + (long long)g * q.rows_per_group * q.lda + ch0;
+#pragma unroll
+      for (int u = 0; u < S; ++u) {
+        const long long row = threadIdx.x + u * kSmallThreads;
+        if (row >= q.rows_per_group) continue;
+        Vec16<T> v; v.from_bits(raw[c][u]);
+        unsigned keep = 0;
+        if constexpr (DROP) keep = drop_keep_mask<EPV>(seed, ((unsigned long long)g * q.rows_per_group + row) * q.c + ch0, q.thr16);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+          float t2 = v.f[j] * sc[j] + sh[j];
+          if constexpr (DROP) t2 = (keep >> j) & 1u ? t2 * q.drop_scale : 0.f;
+          v.f[j] = t2 > 0.f ? t2 : t2 * q.slope;
+        }
+        if (q.s2d_a.d) {
+          long long srow; int blk, border;
+          s2d_cell(q.s2d_a, (long long)g * q.rows_per_group + row, srow, blk, border);
+          v.store(reinterpret_cast<T*>(q.a) + srow * q.lda + (long long)blk * q.s2d_a.cblk + ch0);
+          s2d_zero_siblings<T>(reinterpret_cast<T*>(q.a), q.s2d_a, srow, blk, border, q.lda, ch0);
+        } else v.store(ab + row * q.lda);
+      }
+    }
+  }
+}
+
+template <typename T, bool DROP, int S, int GC>
+__global__ __launch_bounds__(kSmallThreads) void normact_small_res_bwd_kernel(const NormSmallArgs p) {
+  constexpr int EPV = Elem<T>::kPer16B, NV = 2 * GC * EPV;     // sum g | sum g * xhat, per group of the chunk
+  constexpr int CH = NV < 16 ? NV : 16;
+  __shared__ float part[CH * kSmallThreads];
+  __shared__ double total[CH];
+  const NormActArgs& q = p.q;
+  const int ch0 = blockIdx.x * EPV;
+  const unsigned long long seed = DROP ? eff_seed(q.seed, q.seed_ptr) : 0ull;
+  const double inv = 1.0 / (double)q.rows_per_group;
+  const int rows = (int)q.rows_per_group;
+  constexpr int NST = S > 1 ? 3 : 0;                       // S = 8: the last 3 da rows wait in LDS between the passes (each thread its
+  __shared__ uint4 stash[NST ? NST * kSmallThreads : 1];   //  own 16-byte slots, conflict-free; as registers next to z they spilled 13 - 70)
+  __shared__ double tot[kSmallResMaxGroups * 2 * EPV];     // per group (sum g | sum g * xhat), written by thread 0: the sums over the
+                                                           //  groups are formed at the end (as 32 registers of every thread they spilled)
+  for (int g0 = 0; g0 < q.groups; g0 += GC) {
+    BwdConst<EPV> k[GC];
+    uint4 zr[GC][S], dr[GC][S];
+#pragma unroll
+    for (int c = 0; c < GC; ++c) {
+      const int g = g0 + c;
+      load_bwd_const<EPV>(q, g, ch0, k[c]);
+      const T* zb = reinterpret_cast<const T*>(q.z) + (long long)g * q.rows_per_group * q.ldz + ch0;
+      const T* db = reinterpret_cast<const T*>(q.da) + (long long)g * q.rows_per_group * q.ldda + ch0;
+#pragma unroll
+      for (int u = 0; u < S; ++u) {
+        const int row = threadIdx.x + u * kSmallThreads;
+        zr[c][u] = dr[c][u] = make_uint4(0, 0, 0, 0);
+        if (row < rows) {
+          zr[c][u] = *reinterpret_cast<const uint4*>(zb + (long long)row * q.ldz);
+          dr[c][u] = q.s2d_da.d ? *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(q.da) + s2d_offset(q.s2d_da, (long long)g * q.rows_per_group + row, q.ldda) + ch0)
+                                : *reinterpret_cast<const uint4*>(db + (long long)row * q.ldda);
+        }
+      }
+    }
+    float s[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s[i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < GC; ++c)
+#pragma unroll
+      for (int u = 0; u < S; ++u) {
+        const long long row = threadIdx.x + u * kSmallThreads;
+        if (row >= q.rows_per_group) continue;
+        Vec16<T> zv, dv; zv.from_bits(zr[c][u]); dv.from_bits(dr[c][u]);
+        unsigned keep = 0;
+        if constexpr (DROP) keep = drop_keep_mask<EPV>(seed, ((unsigned long long)(g0 + c) * q.rows_per_group + row) * q.c + ch0, q.thr16);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+          float gv, xh;
+          bwd_elem<DROP>(q, (keep >> j) & 1u, k[c].mu[j], k[c].rs[j], k[c].ga[j], k[c].be[j], zv.f[j], dv.f[j], gv, xh);
+          s[(2 * c) * EPV + j] += gv;
+          s[(2 * c + 1) * EPV + j] += gv * xh;
+        }
+        if (u >= S - NST) stash[(u - (S - NST)) * kSmallThreads + threadIdx.x] = dr[c][u];
+      }
+    double t[NV];
+    block_sum_lds<NV, CH>(s, t, part, total);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) tot[g0 * 2 * EPV + i] = t[i];
+    }
+    const bool sub = q.mean && q.batch_stats;
+#pragma unroll
+    for (int c = 0; c < GC; ++c) {
+      const int g = g0 + c;
+      float kk[EPV], m0[EPV], m1[EPV];
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) {
+        const double t0 = t[(2 * c) * EPV + j], t1 = t[(2 * c + 1) * EPV + j];
+        kk[j] = k[c].ga[j] * k[c].rs[j];
+        m0[j] = sub ? (float)(t0 * inv) : 0.f;
+        m1[j] = sub ? (float)(t1 * inv) : 0.f;
+      }
+      T* ob = reinterpret_cast<T*>(q.dz) + (long long)g * q.rows_per_group * q.lddz + ch0;
+#pragma unroll
+      for (int u = 0; u < S; ++u) {
+        const long long row = threadIdx.x + u * kSmallThreads;
+        if (row >= q.rows_per_group) continue;
+        Vec16<T> zv, dv; zv.from_bits(zr[c][u]);
+        if (u >= S - NST) dv.from_bits(stash[(u - (S - NST)) * kSmallThreads + threadIdx.x]); else dv.from_bits(dr[c][u]);
+        unsigned keep = 0;
+        if constexpr (DROP) keep = drop_keep_mask<EPV>(seed, ((unsigned long long)g * q.rows_per_group + row) * q.c + ch0, q.thr16);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+          float gv, xh;
+          bwd_elem<DROP>(q, (keep >> j) & 1u, k[c].mu[j], k[c].rs[j], k[c].ga[j], k[c].be[j], zv.f[j], dv.f[j], gv, xh);
+          zv.f[j] = kk[j] * (gv - m0[j] - xh * m1[j]);
+        }
+        zv.store(ob + row * q.lddz);
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+      const int ch = ch0 + j;
+      if (ch < q.n_affine) {
+        double tb = 0.0, tg = 0.0;
+        for (int g = 0; g < q.groups; ++g) { tb += tot[(2 * g) * EPV + j]; tg += tot[(2 * g + 1) * EPV + j]; }
+        if (p.dgamma) p.dgamma[ch] = p.accumulate ? p.dgamma[ch] + (float)tg : (float)tg;
+        if (p.dbeta) p.dbeta[ch] = p.accumulate ? p.dbeta[ch] + (float)tb : (float)tb;
+      }
+    }
+  }
+}
+
+// S = 1 / 8 row slots per thread and group (s_slots), GC = 1 / 2 groups per chunk (chunk; two groups of 8 slots spilled 100 - 900 registers)
+#define MI355_SMALL_RES_LAUNCH(KERNEL, T, DROP, GC8)                                                                \
+  do {                                                                                                              \
+    if (s_slots == 1) {                                                                                             \
+      if (chunk == 2) KERNEL<T, DROP, 1, 2><<<grid, dim3(kSmallThreads), 0, (hipStream_t)stream>>>(p);              \
+      else KERNEL<T, DROP, 1, 1><<<grid, dim3(kSmallThreads), 0, (hipStream_t)stream>>>(p);                         \
+    } else {                                                                                                        \
+      if (chunk == 2) KERNEL<T, DROP, 8, GC8><<<grid, dim3(kSmallThreads), 0, (hipStream_t)stream>>>(p);            \
+      else KERNEL<T, DROP, 8, 1><<<grid, dim3(kSmallThreads), 0, (hipStream_t)stream>>>(p);                         \
+    }                                                                                                               \
+  } while (0)
+
 // ------------------------------------------------------------------ max-pool 2x2x2
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y,
@@ -2037,6 +2304,17 @@ int mi355_normact_small_fwd(const mi355_normact_small_desc* d, void* stream) {
   p.dgamma = p.dbeta = nullptr; p.accumulate = 0;
   const int epv = d->base.dtype == MI355_DT_F32 ? 4 : 8;
   dim3 grid(d->base.c / epv);
+  if (p.q.rows_per_group <= 8ll * kSmallThreads && p.q.groups <= kSmallResMaxGroups) {       // register-resident form: one load latency per chunk of groups
+    const int s_slots = p.q.rows_per_group <= kSmallThreads ? 1 : 8, chunk = p.q.groups % 2 == 0 ? 2 : 1;
+    if (d->base.dtype == MI355_DT_F32) {
+      if (p.q.thr16) MI355_SMALL_RES_LAUNCH(normact_small_res_fwd_kernel, float, true, 2);
+      else MI355_SMALL_RES_LAUNCH(normact_small_res_fwd_kernel, float, false, 2);
+    } else {
+      if (p.q.thr16) MI355_SMALL_RES_LAUNCH(normact_small_res_fwd_kernel, bf16_t, true, 2);
+      else MI355_SMALL_RES_LAUNCH(normact_small_res_fwd_kernel, bf16_t, false, 2);
+    }
+    return mi355_check_launch("normact_small_fwd");
+  }
   if (d->base.dtype == MI355_DT_F32) {
     if (p.q.thr16) normact_small_fwd_kernel<float, true><<<grid, dim3(kSmallThreads), 0, (hipStream_t)stream>>>(p);
     else normact_small_fwd_kernel<float, false><<<grid, dim3(kSmallThreads), 0, (hipStream_t)stream>>>(p);
@@ -2058,6 +2336,17 @@ int mi355_normact_small_bwd(const mi355_normact_small_desc* d, void* stream) {
   p.dgamma = d->dgamma; p.dbeta = d->dbeta; p.accumulate = d->accumulate;
   const int epv = d->base.dtype == MI355_DT_F32 ? 4 : 8;
   dim3 grid(d->base.c / epv);
+  if (p.q.rows_per_group <= 8ll * kSmallThreads && p.q.groups <= kSmallResMaxGroups) {       // register-resident form: one load latency per chunk of groups
+    const int s_slots = p.q.rows_per_group <= kSmallThreads ? 1 : 8, chunk = p.q.groups % 2 == 0 ? 2 : 1;
+    if (d->base.dtype == MI355_DT_F32) {
+      if (p.q.thr16) MI355_SMALL_RES_LAUNCH(normact_small_res_bwd_kernel, float, true, 1);
+      else MI355_SMALL_RES_LAUNCH(normact_small_res_bwd_kernel, float, false, 1);
+    } else {
+      if (p.q.thr16) MI355_SMALL_RES_LAUNCH(normact_small_res_bwd_kernel, bf16_t, true, 1);
+      else MI355_SMALL_RES_LAUNCH(normact_small_res_bwd_kernel, bf16_t, false, 1);
+    }
+    return mi355_check_launch("normact_small_bwd");
+  }
   if (d->base.dtype == MI355_DT_F32) {
     if (p.q.thr16) normact_small_bwd_kernel<float, true><<<grid, dim3(kSmallThreads), 0, (hipStream_t)stream>>>(p);
     else normact_small_bwd_kernel<float, false><<<grid, dim3(kSmallThreads), 0, (hipStream_t)stream>>>(p);
