@@ -1219,10 +1219,11 @@ __global__ __launch_bounds__(kSmallThreads) void normact_small_res_fwd_kernel(co
     ga[j] = q.gamma ? (ch < q.n_affine ? q.gamma[ch] : 0.f) : 1.f;
     be[j] = (q.beta && ch < q.n_affine) ? q.beta[ch] : 0.f;
   }
-  if (p.batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) p.batches_tracked[0] += q.groups;
+  if (p.batches_tracked && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.batches_tracked[0] += q.groups;
   const double inv = 1.0 / (double)q.rows_per_group;
   const int rows = (int)q.rows_per_group;
-  for (int g0 = 0; g0 < q.groups; g0 += GC) {
+  // blockIdx.y = a chunk of groups when they are independent (no running statistics: the host sets gridDim.y = groups / GC)
+  for (int g0 = blockIdx.y * GC; g0 < q.groups; g0 += gridDim.y * GC) {
     uint4 raw[GC][S];
 #pragma unroll
     for (int c = 0; c < GC; ++c) {
@@ -2306,6 +2307,9 @@ int mi355_normact_small_fwd(const mi355_normact_small_desc* d, void* stream) {
   dim3 grid(d->base.c / epv);
   if (p.q.rows_per_group <= 8ll * kSmallThreads && p.q.groups <= kSmallResMaxGroups) {       // register-resident form: one load latency per chunk of groups
     const int s_slots = p.q.rows_per_group <= kSmallThreads ? 1 : 8, chunk = p.q.groups % 2 == 0 ? 2 : 1;
+    // InstanceNorm (no running statistics, which are a recurrence over the groups): the chunks of groups are independent workgroups --
+    // the reference's batch of 8 patches is 8 groups of 64 - 512 rows, walked 4 chunks deep by c / 8 = 16 - 32 workgroups otherwise
+    if (!p.running_mean) grid.y = (unsigned)(p.q.groups / chunk);
     if (d->base.dtype == MI355_DT_F32) {
       if (p.q.thr16) MI355_SMALL_RES_LAUNCH(normact_small_res_fwd_kernel, float, true, 2);
       else MI355_SMALL_RES_LAUNCH(normact_small_res_fwd_kernel, float, false, 2);
