@@ -345,7 +345,9 @@ int mi355_normact_bwd_apply(const mi355_normact_desc* d, void* stream);
  * fwd: writes a, mean_out / rstd_out [groups][c] (kept for the backward pass) and, for BatchNorm in training mode, the running
  * statistics (momentum update with the unbiased variance, groups in order) and batches_tracked += groups.
  * bwd: base.mean / base.rstd = what fwd wrote; writes dz and the affine gradients (first n_affine channels; `accumulate`
- * adds to what is there).  base.part / base.sums / base.blocks_per_group are unused. */
+ * adds to what is there).  base.sums / base.blocks_per_group are unused.  base.part is unused by fwd; bwd takes it as optional
+ * scratch of groups x 2 x c DOUBLES (8-byte aligned): with it, chunks of statistic groups run as independent workgroups and a
+ * second small launch sums the affine gradients over the groups (same order and precision: bit-identical to the form without). */
 typedef struct mi355_normact_small_desc {
   mi355_normact_desc base;
   float eps, momentum;

@@ -436,6 +436,31 @@ def test_normact_small_resident_forms_equal_the_three_launch_path_with_dropout(h
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,c,sp,drop_p", [(8, 128, (8, 8, 8), 0.0), (8, 256, (4, 4, 4), 0.1), (3, 64, (8, 12, 16), 0.0), (4, 64, (4, 4, 8), 0.1)])
+def test_normact_small_bwd_group_chunks_as_workgroups_bit_identical(hip, dtype, n, c, sp, drop_p):
+    """mi355_normact_small_bwd with scratch for the per-group sums (base.part: the chunks of statistic groups run as independent
+    workgroups, normact_small_affine_kernel sums the affine gradients over the groups) against the form without (one workgroup
+    per 16 bytes of channels walks the groups in order): dz and the affine gradients bit for bit, overwrite and accumulate."""
+    from unet_bssfp_amd import ops
+    assert ops.norm_is_small(n, *sp, c)
+    g = torch.Generator().manual_seed(31)
+    z = to_act(q(torch.randn(n, c, *sp, generator=g) * 1.2 + 0.3, dtype), dtype)
+    da = to_act(q(torch.rand(n, c, *sp, generator=g) - 0.5, dtype), dtype)
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).to(DEV), (torch.rand(c, generator=g) - 0.5).to(DEV)
+    a, mean, rstd = ops.normact_small_fwd(z, n, gamma, beta, 1e-5, 0.1, drop_p, 9)
+    outs = []
+    for scratch in (False, True):
+        dz, dg, db = ops.normact_small_bwd(z, da, n, mean, rstd, gamma, beta, 0.1, drop_p, 9, True, group_scratch=scratch)
+        acc_g, acc_b = torch.full((c,), 0.25, device=DEV), torch.full((c,), -0.5, device=DEV)
+        ops.normact_small_bwd(z, da, n, mean, rstd, gamma, beta, 0.1, drop_p, 9, True, affine_into=(acc_g, acc_b), accumulate=True,
+                              group_scratch=scratch)
+        outs.append((dz, dg, db, acc_g, acc_b))
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
+    assert outs[0][1].abs().max() > 0 and not torch.equal(outs[0][3], outs[0][1])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_batchnorm_eval_mode(hip, dtype):
     from unet_bssfp_amd import functional as Fn
     g = torch.Generator().manual_seed(9)

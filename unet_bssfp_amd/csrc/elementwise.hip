@@ -1326,7 +1326,10 @@ __global__ __launch_bounds__(kSmallThreads) void normact_small_res_bwd_kernel(co
   __shared__ uint4 stash[NST ? NST * kSmallThreads : 1];   //  own 16-byte slots, conflict-free; as registers next to z they spilled 13 - 70)
   __shared__ double tot[kSmallResMaxGroups * 2 * EPV];     // per group (sum g | sum g * xhat), written by thread 0: the sums over the
                                                            //  groups are formed at the end (as 32 registers of every thread they spilled)
-  for (int g0 = 0; g0 < q.groups; g0 += GC) {
+  // blockIdx.y = a chunk of groups when the host gave scratch for the per-group sums (q.part: [groups][2][c] doubles); the affine
+  // gradients are then summed over the groups, in the same order and in f64, by normact_small_affine_kernel
+  double* const gpart = reinterpret_cast<double*>(q.part);
+  for (int g0 = blockIdx.y * GC; g0 < q.groups; g0 += gridDim.y * GC) {
     BwdConst<EPV> k[GC];
     uint4 zr[GC][S], dr[GC][S];
 #pragma unroll
@@ -1371,7 +1374,10 @@ __global__ __launch_bounds__(kSmallThreads) void normact_small_res_bwd_kernel(co
     block_sum_lds<NV, CH>(s, t, part, total);
     if (threadIdx.x == 0) {
 #pragma unroll
-      for (int i = 0; i < NV; ++i) tot[g0 * 2 * EPV + i] = t[i];
+      for (int i = 0; i < NV; ++i) {
+        if (gpart) gpart[((long long)g0 * 2 + i / EPV) * q.c + ch0 + i % EPV] = t[i];
+        else tot[g0 * 2 * EPV + i] = t[i];
+      }
     }
     const bool sub = q.mean && q.batch_stats;
 #pragma unroll
@@ -1404,7 +1410,7 @@ __global__ __launch_bounds__(kSmallThreads) void normact_small_res_bwd_kernel(co
       }
     }
   }
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && !gpart) {
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
       const int ch = ch0 + j;
@@ -1416,6 +1422,18 @@ __global__ __launch_bounds__(kSmallThreads) void normact_small_res_bwd_kernel(co
       }
     }
   }
+}
+
+// the affine gradients of the form above with blockIdx.y = chunk of groups: sum over the groups in order, in f64 (what thread 0 of
+// the single-workgroup form does from its LDS totals: bit-identical)
+__global__ __launch_bounds__(256) void normact_small_affine_kernel(const double* __restrict__ gpart, int groups, int c, int n_affine,
+                                                                   float* dgamma, float* dbeta, int accumulate) {
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= n_affine) return;
+  double tb = 0.0, tg = 0.0;
+  for (int g = 0; g < groups; ++g) { tb += gpart[((long long)g * 2 + 0) * c + ch]; tg += gpart[((long long)g * 2 + 1) * c + ch]; }
+  if (dgamma) dgamma[ch] = accumulate ? dgamma[ch] + (float)tg : (float)tg;
+  if (dbeta) dbeta[ch] = accumulate ? dbeta[ch] + (float)tb : (float)tb;
 }
 
 // S = 1 / 8 row slots per thread and group (s_slots), GC = 1 / 2 groups per chunk (chunk; two groups of 8 slots spilled 100 - 900 registers)
@@ -2342,6 +2360,10 @@ int mi355_normact_small_bwd(const mi355_normact_small_desc* d, void* stream) {
   dim3 grid(d->base.c / epv);
   if (p.q.rows_per_group <= 8ll * kSmallThreads && p.q.groups <= kSmallResMaxGroups) {       // register-resident form: one load latency per chunk of groups
     const int s_slots = p.q.rows_per_group <= kSmallThreads ? 1 : 8, chunk = p.q.groups % 2 == 0 ? 2 : 1;
+    // scratch for the per-group sums given (base.part: groups x 2 x c doubles): the chunks of groups are independent workgroups and the
+    // affine gradients are summed over the groups by a second, tiny launch
+    const bool split = d->base.part != nullptr && p.q.groups / chunk > 1;
+    if (split) grid.y = (unsigned)(p.q.groups / chunk); else p.q.part = nullptr;
     if (d->base.dtype == MI355_DT_F32) {
       if (p.q.thr16) MI355_SMALL_RES_LAUNCH(normact_small_res_bwd_kernel, float, true, 1);
       else MI355_SMALL_RES_LAUNCH(normact_small_res_bwd_kernel, float, false, 1);
@@ -2349,6 +2371,9 @@ int mi355_normact_small_bwd(const mi355_normact_small_desc* d, void* stream) {
       if (p.q.thr16) MI355_SMALL_RES_LAUNCH(normact_small_res_bwd_kernel, bf16_t, true, 1);
       else MI355_SMALL_RES_LAUNCH(normact_small_res_bwd_kernel, bf16_t, false, 1);
     }
+    if (split && (p.dgamma || p.dbeta) && p.q.n_affine > 0)
+      normact_small_affine_kernel<<<dim3((p.q.n_affine + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
+          reinterpret_cast<const double*>(d->base.part), p.q.groups, p.q.c, p.q.n_affine, p.dgamma, p.dbeta, p.accumulate);
     return mi355_check_launch("normact_small_bwd");
   }
   if (d->base.dtype == MI355_DT_F32) {

@@ -774,9 +774,10 @@ def normact_small_fwd(z, groups, gamma, beta, eps, slope, drop_p=0.0, seed=0, se
 
 
 def normact_small_bwd(z, da, groups, mean, rstd, gamma, beta, slope, drop_p, seed, batch_stats, s2d=False, seed_t=None,
-                      affine_into=None, accumulate=False, want_affine=True):
+                      affine_into=None, accumulate=False, want_affine=True, group_scratch=None):
     """Backward of the above in ONE launch: returns (dz, dgamma, dbeta) -- the affine gradients are None when written into
-    ``affine_into`` (caller-owned f32 vectors of the real channel count) or not wanted."""
+    ``affine_into`` (caller-owned f32 vectors of the real channel count) or not wanted.  ``group_scratch`` (None: for three or
+    more statistic groups): hand the kernel scratch for per-group sums, see below."""
     require_cuda(z, da, mean, rstd)
     n, dd, h, w, c = z.shape
     d = _lib.NormSmallDesc()
@@ -799,6 +800,12 @@ def normact_small_bwd(z, da, groups, mean, rstd, gamma, beta, slope, drop_p, see
         dgamma = torch.zeros((c,), dtype=torch.float32, device=z.device)
         dbeta = torch.zeros((c,), dtype=torch.float32, device=z.device)
         d.dgamma, d.dbeta, d.accumulate = dgamma.data_ptr(), dbeta.data_ptr(), 0
+    # three or more statistic groups (the reference's batch of 8 patches): scratch for the per-group sums, so that the chunks of
+    # groups run as independent workgroups and a second tiny launch sums the affine gradients over the groups (same order, f64)
+    gpart = None
+    if (groups >= 3) if group_scratch is None else group_scratch:
+        gpart = torch.empty((groups, 2, c), dtype=torch.float64, device=z.device)
+        d.base.part = gpart.data_ptr()
     after = _norm_probe("bwd", z, gamma)
     _lib.check(_lib.load().mi355_normact_small_bwd(C.byref(d), _stream()), "normact_small_bwd")
     if after is not None:
