@@ -123,6 +123,7 @@ CONV_CASES = [
     ("k3_lowg_8", 1, (256,), 128, (8, 8, 8), 3, 1, 1),               # 8^3: one 8x8x8 tile
     ("k3_lowg_ragged", 2, (64, 64), 64, (10, 10, 10), 3, 1, 1),      # 160^3 configuration's 10^3 level: partial tiles, two samples
     ("k3_lowg_w12", 1, (64,), 192, (5, 9, 12), 3, 1, 1),             # ragged 4x8x16 tiles, three output-channel blocks of 64
+    ("k3_lowg_20", 1, (128, 128), 128, (20, 20, 20), 3, 1, 1),       # 160^3 configuration's 20^3 level (upcat_4.conv_0): ragged 4x8x16 tiles (rows of 20)
     ("k4s2", 1, (30,), 32, (8, 8, 16), 4, 2, 1),
     ("k4s2_ct2", 2, (32,), 64, (8, 8, 8), 4, 2, 1),
     ("k1_head", 2, (24,), 24, (4, 4, 8), 1, 1, 0),
@@ -181,7 +182,7 @@ BF16_PLANS = {
     "k3_ru_ct1": 32041, "k3_ru_cout96": 32041, "k3_ru_ragged_concat": 32141, "k3_ru_ct2_n2": 31942,
     "k3_mg_96to32": 32141, "k3_mg_ragged": 32141, "k3_mg_64to64": 32141, "k3_mg_n2_cout96": 32141, "k3_mg_128to64": 32141,
     "k3_mg_rows2": 32121, "k3_mg_256to128": 32141,
-    "k3_small": 32342, "k3_splitk": 32342, "k3_lowg_16": 32242, "k3_lowg_8": 32342, "k3_lowg_ragged": 32242, "k3_lowg_w12": 32242,
+    "k3_small": 32342, "k3_splitk": 32342, "k3_lowg_16": 32242, "k3_lowg_8": 32342, "k3_lowg_ragged": 32242, "k3_lowg_w12": 32242, "k3_lowg_20": 32242,
 }
 
 

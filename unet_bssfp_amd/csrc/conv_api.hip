@@ -52,7 +52,7 @@ int tune_low_min() { static const int v = env_int("MI355_LOW_MIN", 512); return 
 int tune_lowg() { static const int v = env_int("MI355_LOWG", 1); return v; }          // 0: the low levels stay on conv_halo_kernel
 int tune_lowg_target() { static const int v = env_int("MI355_LOWG_TARGET", 256); return v; }
 int tune_lowg_minch() { static const int v = env_int("MI355_LOWG_MINCH", 4); return v; }     // least 16-channel chunks
-int tune_lowg_maxw() { static const int v = env_int("MI355_LOWG_MAXW", 16); return v; }      // widest row the low-level plans take
+int tune_lowg_maxw() { static const int v = env_int("MI355_LOWG_MAXW", 20); return v; }      // widest row the low-level plans take
 int tune_gather_split() { static const int v = env_int("MI355_GATHER_SPLIT", 1); return v; }
 #else
 constexpr int forced_ct() { return 0; }
@@ -66,7 +66,9 @@ constexpr int tune_low_min() { return 512; }
 constexpr int tune_lowg() { return 1; }
 constexpr int tune_lowg_target() { return 256; }
 constexpr int tune_lowg_minch() { return 4; }
-constexpr int tune_lowg_maxw() { return 16; }
+// (20: the 20^3 level of a 160^3 volume -- BASELINE configs[4] -- is 2.56x its own work in conv_marchg_kernel's 16 x 32 footprints;
+//  1x24x160^3 step, interleaved A/B of the diagnostic build: 16 -> 18.45 ms, 20 -> 17.90, 40 -> 18.03: profiles/r04c_ab_160_lowg_maxw.txt)
+constexpr int tune_lowg_maxw() { return 20; }
 constexpr int tune_gather_split() { return 1; }
 #endif
 
