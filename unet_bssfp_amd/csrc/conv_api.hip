@@ -340,7 +340,11 @@ int make_plan(const mi355_conv_desc* d, Plan* p) {
     const int fk = forced_ksplit();
     const bool lowg = p->shape == 12 || p->shape == 13;       // one workgroup per CU: aim at 256 of them, down to one chunk each
     if ((fk == 0 && (lowg ? wgs < tune_lowg_target() : ((wgs < 256 && nchunks >= 8) || (wgs <= 512 && nchunks >= 16)))) || fk > 1) {   // (32^3 x 128 ch measured slower split)
-      long long ks = lowg ? (tune_lowg_target() + wgs - 1) / wgs : (tune_ks_target() + wgs - 1) / wgs;
+      // low-level plan: the LARGEST split that still fits one round of tune_lowg_target() workgroups (rounded up, 60 workgroups -- the
+      // 20^3 level of a 160^3 volume -- became 5 x 60 = 300: a second round for 44 of them; 24 at 10^3 became 264).  Same splits as
+      // before wherever the count divides 256 (every low level of a 128^3 or 64^3 volume); 160^3: 17.99 -> 17.67 ms with the target
+      // swept to the same effect (profiles/r04c_ab_lowg_target.txt)
+      long long ks = lowg ? std::max(1ll, (long long)tune_lowg_target() / wgs) : (tune_ks_target() + wgs - 1) / wgs;
       if (fk > 1) ks = fk;
       if (ks > (lowg ? nchunks : nchunks / 2)) ks = lowg ? nchunks : nchunks / 2;
       if (ks > 32) ks = 32;
